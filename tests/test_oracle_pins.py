@@ -1,0 +1,188 @@
+"""Pins for the CPU oracle (no GPU).
+
+Pinned against the reference's own code (the four self-contained files built
+unmodified into oracle/_ref/libprestoref.so): Fresnel integrals, the quickselect
+median, and the chi^2 / normal routines behind power_for_sigma and
+candidate_sigma.  Pinned against mathematics: the z-response versus quadrature
+of its defining integral, the FFT versus a double-precision DFT.  Pinned against
+numbers recorded from a run of the reference program (tests/golden/setup_tables.json):
+half-widths, FFT lengths, block counts, numindep and powcut tables.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def ref(oracle):
+    r = oracle.ref_lib()
+    if r is None:
+        pytest.skip("oracle/_ref/libprestoref.so not built (reference tree absent)")
+    return r
+
+
+def test_fresnel_matches_reference(oracle, ref):
+    L = oracle.lib()
+    xs = np.concatenate([np.linspace(-60, 60, 4001), [0.0, 1.6, 1.6007, 36974.0, 36975.0, 1e-9],
+                         np.random.default_rng(1).uniform(-400, 400, 2000)])
+    for x in xs:
+        s1, c1, s2, c2 = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        L.orc_fresnel(x, C.byref(s1), C.byref(c1))
+        ref.fresnl(x, C.byref(s2), C.byref(c2))
+        assert s1.value == s2.value and c1.value == c2.value, x
+
+
+def test_median_matches_reference(oracle, ref):
+    rng = np.random.default_rng(2)
+    for n in (1, 2, 3, 4, 5, 10, 101, 3768, 3964, 4096, 5176):
+        for rep in range(3):
+            a = rng.exponential(1.0, n).astype(np.float32)
+            if rep == 2:
+                a[: n // 2] = a[0]            # heavy ties
+            b = a.copy()
+            got = oracle.median(a)
+            want = float(ref.median(b.ctypes.data_as(C.c_void_p), n))
+            assert got == want
+            assert got == float(np.sort(a)[(n - 1) // 2])
+
+
+def _ref_power_for_sigma(ref, sigma, numsum, numtrials):
+    d, i = C.c_double, C.c_int
+    which, status = i(1), i(0)
+    p, q, x, bound, mean, sd = d(), d(), d(sigma), d(), d(0.0), d(1.0)
+    ref.cdfnor(C.byref(which), C.byref(p), C.byref(q), C.byref(x), C.byref(mean), C.byref(sd),
+               C.byref(status), C.byref(bound))
+    assert status.value == 0
+    q = d(q.value / numtrials)
+    p = d(1.0 - q.value)
+    which, status, df = i(2), i(0), d(2.0 * numsum)
+    ref.cdfchi(C.byref(which), C.byref(p), C.byref(q), C.byref(x), C.byref(df), C.byref(status),
+               C.byref(bound))
+    assert status.value == 0
+    return 0.5 * x.value
+
+
+def _ref_candidate_sigma(ref, power, numsum, numtrials):
+    """candidate_sigma() of the reference for the non-asymptotic branch."""
+    d, i = C.c_double, C.c_int
+    which, status = i(1), i(0)
+    p, q, x, df, bound = d(), d(), d(2.0 * power), d(2.0 * numsum), d()
+    ref.cdfchi(C.byref(which), C.byref(p), C.byref(q), C.byref(x), C.byref(df), C.byref(status),
+               C.byref(bound))
+    assert status.value == 0
+    logp = np.log(q.value) + np.log(numtrials)
+    qq = np.exp(logp)
+    pp = 1.0 - qq
+    if pp <= 0:
+        return 0.0
+    which, status = i(2), i(0)
+    p, q, x, mean, sd = d(pp), d(qq), d(), d(0.0), d(1.0)
+    ref.cdfnor(C.byref(which), C.byref(p), C.byref(q), C.byref(x), C.byref(mean), C.byref(sd),
+               C.byref(status), C.byref(bound))
+    assert status.value == 0
+    return max(x.value, 0.0)
+
+
+def test_power_for_sigma_matches_reference(oracle, ref):
+    L = oracle.lib()
+    nbad_float = 0
+    cases = [(s, nh, nt) for s in (1.0, 2.0, 3.5, 6.0) for nh in (1, 2, 4, 8, 16, 32)
+             for nt in (1e3, 524183.0, 15236347.0, 243781563.0, 5831448272.0)]
+    for s, nh, nt in cases:
+        got = L.orc_power_for_sigma(s, nh, nt)
+        want = _ref_power_for_sigma(ref, s, nh, nt)
+        assert abs(got - want) <= 2e-8 * want, (s, nh, nt, got, want)   # DCDFLIB stops at 1e-8
+        nbad_float += np.float32(got) != np.float32(want)
+    # the float powcut the search uses is the same value in (nearly) every case
+    assert nbad_float <= len(cases) // 10
+
+
+def test_candidate_sigma_matches_reference(oracle, ref):
+    L = oracle.lib()
+    rng = np.random.default_rng(3)
+    for nh in (1, 2, 4, 8, 16, 32):
+        for nt in (65522.0, 15236347.0, 2901241976.0):
+            for power in np.concatenate([rng.uniform(nh * 0.2, nh * 14.5, 40), [nh * 1.0]]):
+                got = L.orc_candidate_sigma(float(power), nh, nt)
+                want = _ref_candidate_sigma(ref, float(power), nh, nt)
+                assert abs(got - want) <= 1e-9 * max(1.0, want), (power, nh, nt, got, want)
+
+
+def test_candidate_sigma_asymptotic_branch_is_continuous(oracle):
+    # chi2/dof > 15 switches to the A&S expansions (src/characteristics.c:504-509):
+    # the two branches must agree where they meet, and sigma must keep rising.
+    L = oracle.lib()
+    for nh in (1, 4, 16):
+        lo = L.orc_candidate_sigma(nh * 14.999, nh, 1e6)
+        hi = L.orc_candidate_sigma(nh * 15.001, nh, 1e6)
+        assert 0 <= hi - lo < 2e-2
+        big = [L.orc_candidate_sigma(nh * f, nh, 1e6) for f in (20, 50, 200, 1000)]
+        assert all(b > a for a, b in zip(big, big[1:]))
+
+
+def test_z_response_is_the_chirp_integral(oracle):
+    L = oracle.lib()
+    u = (np.arange(40000) + 0.5) / 40000
+    for z in (2.0, -2.0, 37.0, -50.0, 200.0, -200.0, 300.0, 1200.0, -1200.0):
+        m = L.orc_z_resp_halfwidth(z)
+        nk = 4 * m
+        k = oracle.gen_z_response(z, nk)
+        r = (-0.5 * z + nk / 4.0) - np.arange(nk) * 0.5
+        idx = np.unique(np.concatenate([np.arange(0, nk, max(nk // 60, 1)), [nk // 2, nk - 1]]))
+        ph = np.outer(r[idx], u) + 0.5 * z * u * u
+        want = np.exp(2j * np.pi * ph).mean(axis=1)
+        assert np.abs(want - k[idx]).max() < 2e-6, z
+    # z = 0 falls through to the sinc kernel
+    k0 = oracle.gen_z_response(0.0, 64)
+    r = (64 / 4.0) - np.arange(64) * 0.5
+    want = np.where(r == 0, 1.0, np.sin(np.pi * r) / np.where(r == 0, 1, np.pi * r)) * np.exp(1j * np.pi * r)
+    assert np.abs(k0 - want).max() < 1e-6
+
+
+def test_fft_against_double_dft(oracle):
+    rng = np.random.default_rng(4)
+    for n in (2, 4, 8, 64, 128, 4096, 8192, 16384):
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        f = np.fft.fft(x.astype(np.complex128))
+        b = np.fft.ifft(x.astype(np.complex128)) * n
+        assert np.abs(oracle.fft(x, -1) - f).max() <= 4e-7 * np.abs(f).max() * np.log2(n)
+        assert np.abs(oracle.fft(x, +1) - b).max() <= 4e-7 * np.abs(b).max() * np.log2(n)
+
+
+def test_setup_tables(oracle):
+    """Shapes and thresholds recorded from the reference program (golden file)."""
+    L = oracle.lib()
+    g = json.load(open(os.path.join(HERE, "golden", "setup_tables.json")))
+    for z, m in g["halfwidth"].items():
+        assert L.orc_z_resp_halfwidth(float(z)) == m
+    for z, n in g["fftlen"].items():
+        assert L.orc_calc_fftlen(1, 1, int(z)) == n
+    for c in g["configs"]:
+        fft = np.zeros(16, dtype=np.complex64)          # never dereferenced here
+        s = oracle.Search.__new__(oracle.Search)
+        s.fft = fft
+        s.obs = oracle.Obs()
+        rc = L.orc_obs_init(C.byref(s.obs), fft.ctypes.data_as(C.c_void_p), c["numbins"],
+                            2 * c["numbins"], c["dt"], c["zmax"], c["numharm"], 2.0, 1.0, 1e9,
+                            0, 0, 0, 0)
+        assert rc == 0
+        assert s.obs.rlo == c["rlo"] and s.obs.numz == c["numz"] and s.obs.fftlen == c["fftlen"]
+        assert s.num_blocks == c["blocks"] and s.num_prepop == c["prepop"]
+        assert abs(s.obs.rlen * s.obs.numz * 4 / 1e9 - c["plane_gb"]) <= 1.2e-2 * c["plane_gb"]
+        assert list(s.numindep) == c["numindep"]
+        np.testing.assert_allclose(s.powcut, c["powcut"], rtol=2e-5)   # table has 5 digits
+
+
+def test_index_helpers(oracle):
+    L = oracle.lib()
+    # round-half-away-from-zero on the z grid, truncation on the r grid
+    assert L.orc_calc_required_z(0.5, 2.0) == 2 and L.orc_calc_required_z(0.5, -2.0) == -2
+    assert L.orc_calc_required_z(0.25, 2.0) == 0 and L.orc_calc_required_z(0.75, -6.0) == -4
+    assert L.orc_calc_required_r(0.5, 1001.5) == 501.0
+    assert L.orc_calc_required_r(1.0, 536.0) == 536.0
+    assert L.orc_index_from_z(-4.0, -200.0) == 98
