@@ -1,0 +1,189 @@
+/*
+ * accelgpu.h -- C ABI of libaccelgpu.so: the MI355X (gfx950) implementation of
+ * the accelsearch hot path (F-Fdot plane generation, in-memory harmonic
+ * summing, thresholding), plus the host-side candidate bookkeeping that the
+ * reference keeps inside search_ffdotpows().
+ *
+ * Plain C types only.  Every function returns ACCELGPU_OK (0) or a negative
+ * code; accelgpu_last_error() gives the text for the calling thread.  The
+ * reference prints and exit()s on errors (e.g. src/accel_utils.c:895-898,
+ * 1571-1573); a C host maps non-zero returns to that behaviour.
+ *
+ * "ref:" comments name the reference interface each entry point stands in for
+ * (paths relative to the reference tree).
+ *
+ * Threading: one context is used from one host thread at a time.  Work is
+ * queued on the context's HIP stream; calls that return host data synchronise
+ * that stream.
+ */
+#ifndef ACCELGPU_H
+#define ACCELGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACCELGPU_OK            0
+#define ACCELGPU_ERR_ARG      -1   /* bad argument / call order                       */
+#define ACCELGPU_ERR_HIP      -2   /* a HIP runtime call failed                       */
+#define ACCELGPU_ERR_NOMEM    -3   /* device or host allocation failed                */
+#define ACCELGPU_ERR_OVERFLOW -4   /* more hits than the caller's buffer can hold     */
+#define ACCELGPU_ERR_RANGE    -5   /* search range errors of create_accelobs()        */
+
+#define ACCELGPU_USELEN    7470    /* ref: include/accel.h:13 ACCEL_USELEN            */
+#define ACCELGPU_MAXSTAGES 6       /* numharm 1,2,4,8,16,32                           */
+
+typedef struct accelgpu_ctx accelgpu_ctx;
+
+/* One F-Fdot cell whose (summed) power exceeded powcut[stage].
+ * ref: the body of the scan in search_ffdotpows(), src/accel_utils.c:1272-1283.
+ *   numharm = 1 << stage
+ *   r = (rind * 0.5) / numharm          z = (zlo + 2 * zind) / numharm          */
+typedef struct accelgpu_hit {
+    float   power;
+    int32_t stage;
+    int32_t zind;
+    int32_t block;      /* search block index, (rind - 2*rlo) / ACCELGPU_USELEN      */
+    int64_t rind;       /* absolute column in half bins: 2*block_rlo + jj            */
+} accelgpu_hit;
+
+/* ref: struct accelcand, include/accel.h:73-83 (search-time fields). */
+typedef struct accelgpu_cand {
+    float   power;
+    float   sigma;
+    int32_t numharm;
+    int32_t added_order; /* index of the hit that last (re)wrote this candidate      */
+    double  r;
+    double  z;
+} accelgpu_cand;
+
+/* Derived search set-up.  ref: the search-range part of create_accelobs(),
+ * src/accel_utils.c:1524-1670, and struct accelobs, include/accel.h:33-71. */
+typedef struct accelgpu_setup {
+    int64_t N, numbins, lobin, highestbin;
+    int32_t zmax, numz, numharm, numharmstages, fftlen, halfwidth;
+    int32_t num_search_blocks, num_prepop_blocks;
+    double  dt, T, rlo, rhi, zlo, zhi;
+    float   sigma;
+    float   powcut[ACCELGPU_MAXSTAGES];
+    int64_t numindep[ACCELGPU_MAXSTAGES];
+    int64_t rlen;        /* plane row length in floats: (highestbin + USELEN) * 2    */
+    int64_t plane_bytes;
+} accelgpu_setup;
+
+const char *accelgpu_last_error(void);
+const char *accelgpu_version(void);
+
+/* ---- context ----------------------------------------------------------- */
+/* Binds a context (own stream, own device buffers) to HIP device `device`. */
+int accelgpu_create(accelgpu_ctx **ctx, int device);
+void accelgpu_destroy(accelgpu_ctx *ctx);
+/* Use the caller's hipStream_t instead of the context's own (NULL restores it). */
+int accelgpu_set_stream(accelgpu_ctx *ctx, void *hip_stream);
+int accelgpu_synchronize(accelgpu_ctx *ctx);
+
+/* ---- host-side scalar helpers (no GPU needed) --------------------------- */
+/* ref: z_resp_halfwidth(z, LOWACC), src/responses.c:29-65 */
+int accelgpu_z_resp_halfwidth(double z);
+/* ref: calc_fftlen(), src/accel_utils.c:119-132 */
+int accelgpu_calc_fftlen(int numharm, int harmnum, int max_zfull);
+/* ref: candidate_sigma(), src/characteristics.c:548-568 */
+double accelgpu_candidate_sigma(double power, int numsum, double numtrials);
+/* ref: power_for_sigma(), src/characteristics.c:571-604 */
+double accelgpu_power_for_sigma(double sigma, int numsum, double numtrials);
+/* ref: create_accelobs() range/threshold logic, src/accel_utils.c:1524-1641,
+ * with the -flo/-fhi semantics of the generated parser (both always present,
+ * src/accelsearch_cmd.c:54-60).  Fills `out`; no GPU work. */
+int accelgpu_plan(int64_t numbins, int64_t N, double dt, int zmax, int numharm, double sigma,
+                  double flo, double fhi, int64_t lobin, accelgpu_setup *out);
+
+/* ---- kernel bank -------------------------------------------------------- */
+/* Builds (or reuses, if zmax is unchanged) the bank of FFT'd z-response
+ * templates for the fundamental: numz = 2*(zmax/2)+1 kernels of fftlen points.
+ * ref: create_subharminfos()/init_subharminfo()/init_kernel()/gen_z_response()/
+ * place_complex_kernel(), src/accel_utils.c:135-210, src/responses.c:165-322,
+ * src/corr_prep.c:58-80, in-memory branch (fundamental only, :195). */
+int accelgpu_build_kernels(accelgpu_ctx *ctx, int zmax);
+/* Parity getter: copies kernel `zind` (fftlen complex floats) to the host.
+ * ref: kernel.data, include/accel.h:85-92 */
+int accelgpu_get_kernel(accelgpu_ctx *ctx, int zind, float *out_complex);
+
+/* ---- input spectrum ----------------------------------------------------- */
+/* Uploads numbins complex floats (PRESTO .fft layout); bin 0 of the array is
+ * Fourier bin `lobin`.  ref: the mmap of the .fft, src/accel_utils.c:1497-1522,
+ * and get_fourier_amplitudes(), :848-877. */
+int accelgpu_load_fft(accelgpu_ctx *ctx, const float *fft_complex_host, int64_t numbins);
+/* Same, for a spectrum already in device memory (not copied, not owned). */
+int accelgpu_load_fft_device(accelgpu_ctx *ctx, const void *fft_complex_dev, int64_t numbins);
+
+/* ---- search ------------------------------------------------------------- */
+/* Fixes the search geometry and thresholds.  `setup` comes from
+ * accelgpu_plan() (or is filled by a host that ran create_accelobs() itself:
+ * rlo, highestbin, lobin, zmax, numharmstages, powcut[] are what is read).
+ * norm_type 0 = block median (default), nph > 0 selects -photon normalisation.
+ * Allocates the in-HBM plane.  ref: accelobs fields, include/accel.h:33-71;
+ * plane allocation src/accel_utils.c:1652-1670 (sized for HBM, not MAXRAMUSE). */
+int accelgpu_set_search(accelgpu_ctx *ctx, const accelgpu_setup *setup, int norm_type, float nph);
+
+/* Generates the whole fundamental plane: every pre-population block and every
+ * search block of the reference grid (startr = 8 + k*3735 below rlo,
+ * startr = rlo + k*3735 above).  ref: subharm_ffdot_plane(1,1,...) +
+ * fund_to_ffdotplane() over the loops of src/accelsearch.c:143-161,168-188. */
+int accelgpu_fill_plane(accelgpu_ctx *ctx);
+
+/* Harmonic summing and thresholding of every search block, from the plane.
+ * Writes at most max_hits records, sorted in the order the reference visits
+ * cells (block, stage, z row, r); *n_hits is the true count; returns
+ * ACCELGPU_ERR_OVERFLOW if it exceeds max_hits (re-run with a larger buffer).
+ * ref: inmem_add_ffdotpows() + search_ffdotpows() over src/accelsearch.c:176-214. */
+int accelgpu_search_plane(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits,
+                          int64_t *n_hits);
+
+/* accelgpu_fill_plane() followed by accelgpu_search_plane(). */
+int accelgpu_run(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits, int64_t *n_hits);
+
+/* Asynchronous halves of accelgpu_run() for pipelined batches: _launch queues
+ * all GPU work of one trial on the stream and returns; _collect waits for it
+ * and returns the sorted hits. */
+int accelgpu_run_launch(accelgpu_ctx *ctx);
+int accelgpu_run_collect(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits,
+                         int64_t *n_hits);
+
+/* Host replay of the candidate list from sorted hits: sigma for every hit and
+ * the r-sorted list with 15-bin proximity replacement.
+ * `added` (optional, n_hits ints) receives the reference's *added flag per hit
+ * (a line in the .txtcand work file).  ref: candidate_sigma() call and
+ * insert_new_accelcand(), src/accel_utils.c:1281-1290, 301-381. */
+int accelgpu_replay_candidates(const accelgpu_setup *setup, const accelgpu_hit *hits,
+                               int64_t n_hits, accelgpu_cand *cands, int64_t max_cands,
+                               int64_t *n_cands, float *sigma_out, int32_t *added);
+
+/* ---- parity getters ------------------------------------------------------ */
+/* One fundamental block computed on its own: numz*USELEN floats, row-major
+ * [z][r], exactly the ffdotpows.powers matrix.  ref: subharm_ffdot_plane(1,1,
+ * startr, startr+3734.5, ...), src/accel_utils.c:879-1056; *rlo_out = ffdot->rlo. */
+int accelgpu_fund_block(accelgpu_ctx *ctx, double startr, float *powers, int32_t *rlo_out);
+/* The block at search index `block` after harmonic stage `stage` (0 = plain
+ * fundamental), summed from the plane as it stands.  ref: the `fundamental`
+ * matrix after the inmem_add_ffdotpows() calls of stage `stage`,
+ * src/accelsearch.c:189-214. */
+int accelgpu_summed_block(accelgpu_ctx *ctx, int block, int stage, float *powers);
+/* Copies `count` floats of plane row `zind` starting at column `col`. */
+int accelgpu_get_plane(accelgpu_ctx *ctx, int zind, int64_t col, int64_t count, float *out);
+/* Overwrites the same region (tests feed both implementations one plane). */
+int accelgpu_put_plane(accelgpu_ctx *ctx, int zind, int64_t col, int64_t count, const float *in);
+
+/* ---- measurement --------------------------------------------------------- */
+/* With profiling on, every launch of the three hot kernels is bracketed by HIP
+ * events on the context's stream.  accelgpu_get_timings() synchronises and
+ * returns, per kernel, launches since the last reset and their summed ms:
+ * index 0 block-prep, 1 correlate (plane generation), 2 harmonic-sum+threshold. */
+int accelgpu_set_profiling(accelgpu_ctx *ctx, int on);
+int accelgpu_get_timings(accelgpu_ctx *ctx, int64_t launches[3], double total_ms[3], int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

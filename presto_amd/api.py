@@ -1,0 +1,262 @@
+"""ctypes host layer over libaccelgpu.so.
+
+Method names mirror the reference functions they stand in for
+(create_subharminfos, subharm_ffdot_plane, fund_to_ffdotplane,
+inmem_add_ffdotpows, search_ffdotpows; reference include/accel.h:116-147).
+There is no CPU fallback: if the library is missing, loading fails loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libaccelgpu.so")
+USELEN = 7470
+MAXSTAGES = 6
+
+
+class AccelGPUError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("accelgpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Setup(C.Structure):
+    _fields_ = [("N", C.c_int64), ("numbins", C.c_int64), ("lobin", C.c_int64),
+                ("highestbin", C.c_int64),
+                ("zmax", C.c_int32), ("numz", C.c_int32), ("numharm", C.c_int32),
+                ("numharmstages", C.c_int32), ("fftlen", C.c_int32), ("halfwidth", C.c_int32),
+                ("num_search_blocks", C.c_int32), ("num_prepop_blocks", C.c_int32),
+                ("dt", C.c_double), ("T", C.c_double), ("rlo", C.c_double), ("rhi", C.c_double),
+                ("zlo", C.c_double), ("zhi", C.c_double),
+                ("sigma", C.c_float), ("powcut", C.c_float * MAXSTAGES),
+                ("numindep", C.c_int64 * MAXSTAGES),
+                ("rlen", C.c_int64), ("plane_bytes", C.c_int64)]
+
+
+HIT_DTYPE = np.dtype([("power", "f4"), ("stage", "i4"), ("zind", "i4"), ("block", "i4"),
+                      ("rind", "i8")])
+CAND_DTYPE = np.dtype([("power", "f4"), ("sigma", "f4"), ("numharm", "i4"), ("added_order", "i4"),
+                       ("r", "f8"), ("z", "f8")])
+
+_lib = None
+
+
+def build_library():
+    """Compile libaccelgpu.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s"])
+    return LIB_PATH
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run `make -C presto_amd/csrc` (or "
+                          "__graft_entry__.build()).  There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i, i64, d, f = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_float
+    pS = C.POINTER(Setup)
+    L.accelgpu_last_error.restype = C.c_char_p
+    L.accelgpu_version.restype = C.c_char_p
+    L.accelgpu_create.argtypes = [C.POINTER(vp), i]
+    L.accelgpu_destroy.argtypes = [vp]; L.accelgpu_destroy.restype = None
+    L.accelgpu_set_stream.argtypes = [vp, vp]
+    L.accelgpu_synchronize.argtypes = [vp]
+    L.accelgpu_z_resp_halfwidth.argtypes = [d]
+    L.accelgpu_calc_fftlen.argtypes = [i, i, i]
+    L.accelgpu_candidate_sigma.argtypes = [d, i, d]; L.accelgpu_candidate_sigma.restype = d
+    L.accelgpu_power_for_sigma.argtypes = [d, i, d]; L.accelgpu_power_for_sigma.restype = d
+    L.accelgpu_plan.argtypes = [i64, i64, d, i, i, d, d, d, i64, pS]
+    L.accelgpu_build_kernels.argtypes = [vp, i]
+    L.accelgpu_get_kernel.argtypes = [vp, i, vp]
+    L.accelgpu_load_fft.argtypes = [vp, vp, i64]
+    L.accelgpu_load_fft_device.argtypes = [vp, vp, i64]
+    L.accelgpu_set_search.argtypes = [vp, pS, i, f]
+    L.accelgpu_fill_plane.argtypes = [vp]
+    L.accelgpu_search_plane.argtypes = [vp, vp, i64, C.POINTER(i64)]
+    L.accelgpu_run.argtypes = [vp, vp, i64, C.POINTER(i64)]
+    L.accelgpu_run_launch.argtypes = [vp]
+    L.accelgpu_run_collect.argtypes = [vp, vp, i64, C.POINTER(i64)]
+    L.accelgpu_replay_candidates.argtypes = [pS, vp, i64, vp, i64, C.POINTER(i64), vp, vp]
+    L.accelgpu_fund_block.argtypes = [vp, d, vp, C.POINTER(C.c_int32)]
+    L.accelgpu_summed_block.argtypes = [vp, i, i, vp]
+    L.accelgpu_get_plane.argtypes = [vp, i, i64, i64, vp]
+    L.accelgpu_put_plane.argtypes = [vp, i, i64, i64, vp]
+    L.accelgpu_set_profiling.argtypes = [vp, i]
+    L.accelgpu_get_timings.argtypes = [vp, C.POINTER(i64), C.POINTER(d), i]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise AccelGPUError(rc, load_library().accelgpu_last_error().decode())
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def plan(numbins, N, dt, zmax, numharm, sigma=2.0, flo=1.0, fhi=10000.0, lobin=0):
+    """Search set-up as create_accelobs() derives it (no GPU needed)."""
+    s = Setup()
+    _check(load_library().accelgpu_plan(int(numbins), int(N), float(dt), int(zmax), int(numharm),
+                                        float(sigma), float(flo), float(fhi), int(lobin),
+                                        C.byref(s)))
+    return s
+
+
+def candidate_sigma(power, numsum, numtrials):
+    return load_library().accelgpu_candidate_sigma(float(power), int(numsum), float(numtrials))
+
+
+def power_for_sigma(sigma, numsum, numtrials):
+    return load_library().accelgpu_power_for_sigma(float(sigma), int(numsum), float(numtrials))
+
+
+def replay_candidates(setup, hits):
+    """Host replay: returns (cands, sigma per hit, added flag per hit)."""
+    L = load_library()
+    hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+    n = hits.size
+    cap = max(n, 1)
+    cands = np.zeros(cap, dtype=CAND_DTYPE)
+    sig = np.zeros(cap, dtype=np.float32)
+    added = np.zeros(cap, dtype=np.int32)
+    nc = C.c_int64(0)
+    _check(L.accelgpu_replay_candidates(C.byref(setup), _ptr(hits), n, _ptr(cands), cap,
+                                        C.byref(nc), _ptr(sig), _ptr(added)))
+    return cands[:nc.value].copy(), sig[:n], added[:n]
+
+
+class AccelSearchGPU:
+    """One search context on one GPU."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        self._h = C.c_void_p()
+        _check(self.L.accelgpu_create(C.byref(self._h), int(device)))
+        self.setup = None
+        self._keep = None
+
+    def close(self):
+        if self._h:
+            self.L.accelgpu_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- set-up -----------------------------------------------------------
+    def set_stream(self, hip_stream):
+        _check(self.L.accelgpu_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def create_subharminfos(self, zmax):
+        """Build (or reuse) the kernel bank for the fundamental."""
+        _check(self.L.accelgpu_build_kernels(self._h, int(zmax)))
+
+    def kernel(self, zind, fftlen):
+        out = np.empty(fftlen, dtype=np.complex64)
+        _check(self.L.accelgpu_get_kernel(self._h, int(zind), _ptr(out)))
+        return out
+
+    def load_fft(self, spectrum):
+        a = np.ascontiguousarray(spectrum, dtype=np.complex64)
+        _check(self.L.accelgpu_load_fft(self._h, _ptr(a), a.size))
+
+    def load_fft_device(self, dev_ptr, numbins, keepalive=None):
+        """Use a spectrum already in device memory (e.g. a torch tensor's data_ptr())."""
+        self._keep = keepalive
+        _check(self.L.accelgpu_load_fft_device(self._h, C.c_void_p(dev_ptr), int(numbins)))
+
+    def configure(self, numbins, N, dt, zmax, numharm, sigma=2.0, flo=1.0, fhi=10000.0, lobin=0,
+                  photon_nph=0.0):
+        """plan + kernel bank + set_search in one call."""
+        self.setup = plan(numbins, N, dt, zmax, numharm, sigma, flo, fhi, lobin)
+        self.create_subharminfos(self.setup.zmax)
+        _check(self.L.accelgpu_set_search(self._h, C.byref(self.setup), 0, float(photon_nph)))
+        return self.setup
+
+    # -- the hot path -----------------------------------------------------
+    def fill_plane(self):
+        _check(self.L.accelgpu_fill_plane(self._h))
+
+    def _hits_call(self, fn, max_hits):
+        while True:
+            hits = np.empty(max_hits, dtype=HIT_DTYPE)
+            n = C.c_int64(0)
+            rc = fn(self._h, _ptr(hits), max_hits, C.byref(n))
+            if rc == -4 and n.value > max_hits:      # ACCELGPU_ERR_OVERFLOW: grow and repeat
+                max_hits = int(n.value * 1.25) + 1024
+                if fn is self.L.accelgpu_run_collect:
+                    fn = self.L.accelgpu_search_plane
+                continue
+            _check(rc)
+            return hits[:n.value]
+
+    def search_plane(self, max_hits=1 << 20):
+        return self._hits_call(self.L.accelgpu_search_plane, max_hits)
+
+    def run(self, max_hits=1 << 20):
+        _check(self.L.accelgpu_run_launch(self._h))
+        return self._hits_call(self.L.accelgpu_run_collect, max_hits)
+
+    def run_launch(self):
+        _check(self.L.accelgpu_run_launch(self._h))
+
+    def run_collect(self, max_hits=1 << 20):
+        return self._hits_call(self.L.accelgpu_run_collect, max_hits)
+
+    def search(self, max_hits=1 << 20):
+        """Whole search of the loaded spectrum: (hits, cands, sigma, added)."""
+        hits = self.run(max_hits)
+        cands, sig, added = replay_candidates(self.setup, hits)
+        return hits, cands, sig, added
+
+    # -- parity getters -----------------------------------------------------
+    def subharm_ffdot_plane(self, startr):
+        """Fundamental block at startr: (powers[numz, USELEN], rlo)."""
+        out = np.empty((self.setup.numz, USELEN), dtype=np.float32)
+        rlo = C.c_int32(0)
+        _check(self.L.accelgpu_fund_block(self._h, float(startr), _ptr(out), C.byref(rlo)))
+        return out, rlo.value
+
+    def summed_block(self, block, stage):
+        out = np.empty((self.setup.numz, USELEN), dtype=np.float32)
+        _check(self.L.accelgpu_summed_block(self._h, int(block), int(stage), _ptr(out)))
+        return out
+
+    def get_plane(self, zind, col, count):
+        out = np.empty(count, dtype=np.float32)
+        _check(self.L.accelgpu_get_plane(self._h, int(zind), int(col), int(count), _ptr(out)))
+        return out
+
+    def put_plane(self, zind, col, values):
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        _check(self.L.accelgpu_put_plane(self._h, int(zind), int(col), v.size, _ptr(v)))
+
+    def plane(self):
+        rows = [self.get_plane(z, 0, self.setup.rlen) for z in range(self.setup.numz)]
+        return np.stack(rows)
+
+    # -- measurement --------------------------------------------------------
+    def set_profiling(self, on):
+        _check(self.L.accelgpu_set_profiling(self._h, int(bool(on))))
+
+    def timings(self, reset=True):
+        n = (C.c_int64 * 3)()
+        ms = (C.c_double * 3)()
+        _check(self.L.accelgpu_get_timings(self._h, n, ms, int(bool(reset))))
+        names = ("block_prep", "correlate", "harmsum")
+        return {k: dict(launches=int(n[i]), total_ms=float(ms[i])) for i, k in enumerate(names)}
+
+    def synchronize(self):
+        _check(self.L.accelgpu_synchronize(self._h))

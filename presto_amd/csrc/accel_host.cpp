@@ -1,0 +1,331 @@
+// accel_host.cpp -- host-side logic of libaccelgpu: search planning, detection
+// statistics and the candidate-list replay.  No GPU calls in this file.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "accel_host.hpp"
+
+namespace accelhost {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char *last_error() { return g_err; }
+
+// ---- sizes ---------------------------------------------------------------
+int z_resp_halfwidth(double z)
+{
+    // low-accuracy rule of the reference (src/responses.c:55-63): quadratic in
+    // |z| on top of 16 bins, capped at 0.6|z| for |z| > 100
+    z = std::fabs(z);
+    int m = (int) (long) (z * (0.00089 * z + 0.3131) + 16);
+    m = std::max(m, 16);
+    if (z > 100 && m > 0.6 * z)
+        m = (int) (0.6 * z);
+    return m;
+}
+
+static int nearest_int(double x) { return (int) (x < 0 ? x - 0.5 : x + 0.5); }
+
+int calc_required_z(double harm_fract, double zfull)
+{
+    return nearest_int(0.5 * zfull * harm_fract) * 2;
+}
+
+double calc_required_r(double harm_fract, double rfull)
+{
+    return (int) (2 * rfull * harm_fract + 0.5) * 0.5;
+}
+
+int index_from_z(double z, double loz) { return (int) ((z - loz) * 0.5 + 1e-14); }
+
+int calc_fftlen(int numharm, int harmnum, int max_zfull)
+{
+    const double f = (double) harmnum / (double) numharm;
+    const int bins_needed = (ACCELGPU_USELEN * harmnum) / numharm + 2;
+    const int end_effects = 4 * z_resp_halfwidth(calc_required_z(f, max_zfull));
+    long long n = 1;
+    while (n < bins_needed + end_effects)
+        n <<= 1;
+    return (int) n;
+}
+
+// ---- detection statistics --------------------------------------------------
+// Summed power of numsum harmonics is chi^2 with 2*numsum degrees of freedom
+// (in units of power = chi^2/2).  For even dof the survival function is a
+// finite Poisson sum, so no incomplete-gamma library is needed.
+static double chi2_sf_even(double x, int dof)
+{
+    const int k = dof / 2;
+    const double h = 0.5 * x;
+    double term = 1.0, sum = 1.0;
+    for (int j = 1; j < k; j++) {
+        term *= h / j;
+        sum += term;
+    }
+    return std::exp(-h) * sum;
+}
+
+static double chi2_logp(double chi2, int dof)
+{
+    if (chi2 <= 0.0)
+        return -INFINITY;
+    if (chi2 / dof > 15.0 || (dof > 150 && chi2 / dof > 6.0)) {
+        // asymptotic forms used by the reference for large chi^2
+        // (src/characteristics.c:418-453, 504-509; A&S 6.5.32 and 6.1.41)
+        const double a = 0.5 * dof, z = 0.5 * chi2;
+        double x = 1.0, part = 1.0, term = 1.0;
+        for (int ii = 1; std::fabs(part) > 1e-15; ii++) {
+            term *= (a - ii);
+            part = term / std::pow(z, ii);
+            x += part;
+        }
+        const double lig = (a - 1.0) * std::log(z) - z + std::log(x);
+        double lg = (a - 0.5) * std::log(a) - a + 0.91893853320467267;
+        const double y = 1.0 / (a * a);
+        lg += (((-5.9523809523809529e-4 * y + 7.9365079365079365079365e-4) * y -
+                2.7777777777777777777778e-3) * y + 8.3333333333333333333333e-2) / a;
+        return lig - lg;
+    }
+    return std::log(chi2_sf_even(chi2, dof));
+}
+
+static double norm_sf(double x) { return 0.5 * std::erfc(x / M_SQRT2); }
+
+static double norm_isf(double q) // 0 < q < 1
+{
+    if (q == 0.5)
+        return 0.0;
+    const bool flip = q > 0.5;
+    const double qq = flip ? 1.0 - q : q;
+    const double lq = std::log(qq);
+    double t = std::sqrt(-2.0 * lq);
+    double x = t - (2.515517 + t * (0.802853 + t * 0.010328)) /
+                       (1.0 + t * (1.432788 + t * (0.189269 + t * 0.001308)));
+    for (int it = 0; it < 60; it++) {
+        const double Q = norm_sf(x);
+        const double pdf = std::exp(-0.5 * x * x) / std::sqrt(2.0 * M_PI);
+        const double dx = (std::log(Q) - lq) * Q / pdf;
+        x += dx;
+        if (std::fabs(dx) <= 4e-16 * std::max(1.0, std::fabs(x)))
+            break;
+    }
+    return flip ? -x : x;
+}
+
+static double equivalent_gaussian_sigma(double logp)
+{
+    double x;
+    if (logp < -600.0) {
+        // A&S 26.2.23 on log p (src/characteristics.c:397-415)
+        const double t = std::sqrt(-2.0 * logp);
+        x = t - (2.515517 + t * (0.802853 + t * 0.010328)) /
+                    (1.0 + t * (1.432788 + t * (0.189269 + t * 0.001308)));
+    } else {
+        const double q = std::exp(logp), p = 1.0 - q;
+        if (p <= 0.0 || p > 1.0)
+            x = 0.0;  // the reference maps this DCDFLIB range error to 0 (:474-475)
+        else if (q <= 0.0 || q > 1.0)
+            x = 38.5; // and this one to 38.5 (:476-477)
+        else
+            x = norm_isf(q);
+    }
+    return x < 0.0 ? 0.0 : x;
+}
+
+double candidate_sigma(double power, int numsum, double numtrials)
+{
+    if (power <= 0.0)
+        return 0.0;
+    const double logp = chi2_logp(2.0 * power, 2 * numsum) + std::log(numtrials);
+    return equivalent_gaussian_sigma(logp);
+}
+
+double power_for_sigma(double sigma, int numsum, double numtrials)
+{
+    const double lq = std::log(norm_sf(sigma) / numtrials);
+    const int dof = 2 * numsum;
+    double lo = 0.0, hi = 2.0 * dof + 10.0;
+    while (std::log(chi2_sf_even(hi, dof)) > lq)
+        hi *= 2.0;
+    for (int it = 0; it < 200 && hi - lo > 1e-15 * hi; it++) {
+        const double mid = 0.5 * (lo + hi);
+        (std::log(chi2_sf_even(mid, dof)) > lq ? lo : hi) = mid;
+    }
+    return 0.25 * (lo + hi);
+}
+
+// ---- planning --------------------------------------------------------------
+int plan(int64_t numbins, int64_t N, double dt, int zmax, int numharm, double sigma, double flo,
+         double fhi, int64_t lobin, accelgpu_setup *s)
+{
+    std::memset(s, 0, sizeof(*s));
+    if (numbins <= 0 || N <= 0 || dt <= 0 || zmax < 0 || zmax > 1200) {
+        set_error("accelgpu_plan: bad numbins/N/dt/zmax");
+        return ACCELGPU_ERR_ARG;
+    }
+    if (zmax % 2)
+        zmax = (zmax / 2 + 1) * 2;
+    if (numharm != 1 && numharm != 2 && numharm != 4 && numharm != 8 && numharm != 16 &&
+        numharm != 32) {
+        set_error("'numharm' = %d must be a power-of-two!", numharm);
+        return ACCELGPU_ERR_ARG;
+    }
+    s->N = N;
+    s->numbins = numbins;
+    s->lobin = lobin;
+    if (lobin > numbins - 1) {
+        set_error("'lobin' is greater than the total number of frequencies in the data set.");
+        return ACCELGPU_ERR_RANGE;
+    }
+    s->zmax = zmax;
+    s->numz = (zmax / 2) * 2 + 1;
+    s->numharm = numharm;
+    int st = 0;
+    for (int n = numharm; n > 1; n >>= 1)
+        st++;
+    s->numharmstages = st + 1;
+    s->dt = dt;
+    s->T = dt * (double) N;
+    s->rlo = std::floor(flo * s->T);
+    if (s->rlo < (double) lobin)
+        s->rlo = (double) lobin;
+    if (s->rlo > numbins - 1) {
+        set_error("Low frequency to search 'flo' is greater than the highest available frequency.");
+        return ACCELGPU_ERR_RANGE;
+    }
+    s->highestbin = (int64_t) std::ceil(fhi * s->T);
+    if (s->highestbin > numbins - 1)
+        s->highestbin = numbins - 1;
+    s->rhi = (double) s->highestbin;
+    if (s->highestbin < s->rlo) {
+        set_error("High frequency to search 'fhi' is less than the lowest frequency to search 'flo'.");
+        return ACCELGPU_ERR_RANGE;
+    }
+    s->zhi = zmax;
+    s->zlo = -zmax;
+    s->sigma = (float) sigma;
+    for (int ii = 0; ii < s->numharmstages; ii++) {
+        if (s->numz == 1)
+            s->numindep[ii] = (int64_t) ((s->rhi - s->rlo) / (1 << ii));
+        else
+            s->numindep[ii] =
+                (int64_t) ((s->rhi - s->rlo) * (s->numz + 1) * (2.0 / 6.95) / (1 << ii));
+        s->powcut[ii] = (float) power_for_sigma(s->sigma, 1 << ii, (double) s->numindep[ii]);
+    }
+    s->fftlen = calc_fftlen(1, 1, zmax);
+    s->halfwidth = z_resp_halfwidth((double) zmax);
+    s->rlen = (s->highestbin + ACCELGPU_USELEN) * 2;
+    s->plane_bytes = s->rlen * (int64_t) s->numz * 4;
+    const double step = ACCELGPU_USELEN * 0.5;
+    for (double r = 8; r < s->rlo; r += step)
+        s->num_prepop_blocks++;
+    for (double r = s->rlo; r + step < (double) s->highestbin; r += step)
+        s->num_search_blocks++;
+    return ACCELGPU_OK;
+}
+
+// ---- candidate list --------------------------------------------------------
+// The reference keeps an r-ordered singly linked list and, for every hit, walks
+// it from the head to the first entry with r >= rr (or the last entry).  The
+// same walk on a contiguous array gives the same list; entries can fall out of
+// order after an in-place overwrite, so the scan is linear on purpose.
+struct Entry {
+    double r;
+    float sigma, power;
+    int numharm;
+    int order;
+    double z;
+};
+
+int replay(const accelgpu_setup *s, const accelgpu_hit *hits, int64_t n_hits,
+           accelgpu_cand *cands, int64_t max_cands, int64_t *n_cands, float *sigma_out,
+           int32_t *added_out)
+{
+    const double CLOSEST = 15.0;
+    std::vector<Entry> list;
+    list.reserve(1024);
+    const double zlo = s->zlo;
+    for (int64_t i = 0; i < n_hits; i++) {
+        const accelgpu_hit &h = hits[i];
+        if (h.stage < 0 || h.stage >= s->numharmstages) {
+            set_error("accelgpu_replay_candidates: hit %lld has stage %d", (long long) i, h.stage);
+            return ACCELGPU_ERR_ARG;
+        }
+        const int numharm = 1 << h.stage;
+        const float sig =
+            (float) candidate_sigma(h.power, numharm, (double) s->numindep[h.stage]);
+        const double rr = ((double) h.rind * 0.5) / (double) numharm;
+        const double zz = (zlo + h.zind * 2.0) / (double) numharm;
+        if (sigma_out)
+            sigma_out[i] = sig;
+        const Entry e{rr, sig, h.power, numharm, (int) i, zz};
+        int added = 0;
+        if (list.empty()) {
+            list.push_back(e);
+            added = 1;
+        } else {
+            size_t cur = 0;
+            const size_t last = list.size() - 1;
+            while (cur < last && list[cur].r < rr)
+                cur++;
+            const bool has_prev = cur > 0;
+            const double next_diff = std::fabs(rr - list[cur].r);
+            const double prev_diff = has_prev ? std::fabs(rr - list[cur - 1].r) : CLOSEST + 1.0;
+            if (prev_diff < CLOSEST) {
+                if (list[cur - 1].sigma < sig) {
+                    list[cur - 1] = e;
+                    added = 1;
+                }
+                if (next_diff < CLOSEST && list[cur].sigma < sig) {
+                    if (added) {
+                        list.erase(list.begin() + cur);
+                    } else {
+                        list[cur] = e;
+                        added = 1;
+                    }
+                }
+            } else if (next_diff < CLOSEST) {
+                if (list[cur].sigma < sig) {
+                    list[cur] = e;
+                    added = 1;
+                }
+            } else {
+                added = 1;
+                if (cur == last && list[cur].r < rr - CLOSEST)
+                    list.push_back(e);
+                else
+                    list.insert(list.begin() + cur, e); // before cur (also the new-head case)
+            }
+        }
+        if (added_out)
+            added_out[i] = added;
+    }
+    *n_cands = (int64_t) list.size();
+    if ((int64_t) list.size() > max_cands) {
+        set_error("accelgpu_replay_candidates: %zu candidates, room for %lld", list.size(),
+                  (long long) max_cands);
+        return ACCELGPU_ERR_OVERFLOW;
+    }
+    for (size_t i = 0; i < list.size(); i++) {
+        cands[i].power = list[i].power;
+        cands[i].sigma = list[i].sigma;
+        cands[i].numharm = list[i].numharm;
+        cands[i].added_order = list[i].order;
+        cands[i].r = list[i].r;
+        cands[i].z = list[i].z;
+    }
+    return ACCELGPU_OK;
+}
+
+} // namespace accelhost

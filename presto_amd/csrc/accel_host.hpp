@@ -1,0 +1,23 @@
+// accel_host.hpp -- host-side helpers of libaccelgpu (no GPU calls).
+#pragma once
+#include <stdint.h>
+#include "accelgpu.h"
+
+namespace accelhost {
+
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+const char *last_error();
+
+int z_resp_halfwidth(double z);
+int calc_required_z(double harm_fract, double zfull);
+double calc_required_r(double harm_fract, double rfull);
+int index_from_z(double z, double loz);
+int calc_fftlen(int numharm, int harmnum, int max_zfull);
+double candidate_sigma(double power, int numsum, double numtrials);
+double power_for_sigma(double sigma, int numsum, double numtrials);
+int plan(int64_t numbins, int64_t N, double dt, int zmax, int numharm, double sigma, double flo,
+         double fhi, int64_t lobin, accelgpu_setup *out);
+int replay(const accelgpu_setup *s, const accelgpu_hit *hits, int64_t n_hits, accelgpu_cand *cands,
+           int64_t max_cands, int64_t *n_cands, float *sigma_out, int32_t *added_out);
+
+} // namespace accelhost

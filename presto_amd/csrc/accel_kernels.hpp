@@ -1,0 +1,425 @@
+// accel_kernels.hpp -- gfx950 kernels of the acceleration-search hot path.
+//
+//   k_gen_zresp      z-response templates in fp64 (gen_z_response / gen_r_response,
+//                    reference src/responses.c:165-322) placed for correlation
+//                    (place_complex_kernel, src/corr_prep.c:58-80)
+//   k_fft_rows       forward FFT of each placed template (init_kernel, src/accel_utils.c:150)
+//   k_block_prep     per block: window fetch, exact block-median normalisation,
+//                    forward FFT (src/accel_utils.c:929-983)
+//   k_correlate      per (z, block): template multiply, inverse FFT, |.|^2 / N^2,
+//                    row store into the plane (src/accel_utils.c:1002-1051, 1076-1090)
+//   k_harmsum        in-memory harmonic sum + threshold + wave-ballot compaction
+//                    (src/accel_utils.c:1160-1208, 1259-1299)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fft_lds.hpp"
+
+namespace accelk {
+
+using afft::c32;
+
+constexpr int USELEN = 7470;
+
+struct DevHit {          // 16 bytes, written by k_harmsum
+    float power;
+    uint32_t stage_zind; // stage << 16 | zind
+    int64_t rind;
+};
+
+// ---------------------------------------------------------------------------
+// Fresnel integrals in fp64 (Cephes rational approximations, the same ones the
+// reference's src/fresnl.c:175-216 evaluates).
+// ---------------------------------------------------------------------------
+__device__ inline double horner(double x, const double *c, int n)
+{
+    double acc = c[0];
+    for (int k = 1; k < n; k++)
+        acc = acc * x + c[k];
+    return acc;
+}
+__device__ inline double horner1(double x, const double *c, int n)
+{
+    double acc = x + c[0];
+    for (int k = 1; k < n; k++)
+        acc = acc * x + c[k];
+    return acc;
+}
+
+__device__ inline void fresnel(double xin, double *S, double *C)
+{
+    const double sn[6] = {-2.99181919401019853726E3, 7.08840045257738576863E5,
+                          -6.29741486205862506537E7, 2.54890880573376359104E9,
+                          -4.42979518059697779103E10, 3.18016297876567817986E11};
+    const double sd[6] = {2.81376268889994315696E2, 4.55847810806532581675E4,
+                          5.17343888770096400730E6, 4.19320245898111231129E8,
+                          2.24411795645340920940E10, 6.07366389490084639049E11};
+    const double cn[6] = {-4.98843114573573548651E-8, 9.50428062829859605134E-6,
+                          -6.45191435683965050962E-4, 1.88843319396703850064E-2,
+                          -2.05525900955013891793E-1, 9.99999999999999998822E-1};
+    const double cd[7] = {3.99982968972495980367E-12, 9.15439215774657478799E-10,
+                          1.25001862479598821474E-7, 1.22262789024179030997E-5,
+                          8.68029542941784300606E-4, 4.12142090722199792936E-2,
+                          1.00000000000000000118E0};
+    const double fn[10] = {4.21543555043677546506E-1, 1.43407919780758885261E-1,
+                           1.15220955073585758835E-2, 3.45017939782574027900E-4,
+                           4.63613749287867322088E-6, 3.05568983790257605827E-8,
+                           1.02304514164907233465E-10, 1.72010743268161828879E-13,
+                           1.34283276233062758925E-16, 3.76329711269987889006E-20};
+    const double fd[10] = {7.51586398353378947175E-1, 1.16888925859191382142E-1,
+                           6.44051526508858611005E-3, 1.55934409164153020873E-4,
+                           1.84627567348930545870E-6, 1.12699224763999035261E-8,
+                           3.60140029589371370404E-11, 5.88754533621578410010E-14,
+                           4.52001434074129701496E-17, 1.25443237090011264384E-20};
+    const double gn[11] = {5.04442073643383265887E-1, 1.97102833525523411709E-1,
+                           1.87648584092575249293E-2, 6.84079380915393090172E-4,
+                           1.15138826111884280931E-5, 9.82852443688422223854E-8,
+                           4.45344415861750144738E-10, 1.08268041139020870318E-12,
+                           1.37555460633261799868E-15, 8.36354435630677421531E-19,
+                           1.86958710162783235106E-22};
+    const double gd[11] = {1.47495759925128324529E0, 3.37748989120019970451E-1,
+                           2.53603741420338795122E-2, 8.14679107184306179049E-4,
+                           1.27545075667729118702E-5, 1.04314589657571990585E-7,
+                           4.60680728146520428211E-10, 1.10273215066240270757E-12,
+                           1.38796531259578871258E-15, 8.39158816283118707363E-19,
+                           1.86958710162783236342E-22};
+    const double PI = 3.14159265358979323846;
+    const double x = fabs(xin), x2 = x * x;
+    double ss, cc;
+    if (x2 < 2.5625) {
+        const double t = x2 * x2;
+        ss = x * x2 * horner(t, sn, 6) / horner1(t, sd, 6);
+        cc = x * horner(t, cn, 6) / horner(t, cd, 7);
+    } else if (x > 36974.0) {
+        ss = cc = 0.5;
+    } else {
+        double t = PI * x2;
+        const double u = 1.0 / (t * t);
+        t = 1.0 / t;
+        const double f = 1.0 - u * horner(u, fn, 10) / horner1(u, fd, 10);
+        const double g = t * horner(u, gn, 11) / horner1(u, gd, 11);
+        double s, c;
+        sincos(0.5 * PI * x2, &s, &c);
+        const double pix = PI * x;
+        cc = 0.5 + (f * s - g * c) / pix;
+        ss = 0.5 - (f * c + g * s) / pix;
+    }
+    *S = xin < 0.0 ? -ss : ss;
+    *C = xin < 0.0 ? -cc : cc;
+}
+
+// One thread per template sample.  Sample ii of kernel zi (z = -zmax + 2*zi,
+// numkern = 4*m(z) samples at half-bin spacing, roffset = 0) goes to its wrapped
+// position in a zero-filled row of `fftlen` points: the second half of the
+// response first, the first half at the tail.
+__global__ void k_gen_zresp(c32 *__restrict__ bank, const int *__restrict__ halfwidths, int zmax,
+                            int fftlen, int max_numkern)
+{
+    const int zi = blockIdx.y;
+    const int ii = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = halfwidths[zi];
+    const int numkern = 4 * m;
+    if (ii >= numkern)
+        return;
+    const double PI = 3.14159265358979323846;
+    const double z = (double) (-zmax + 2 * zi);
+    const double absz = fabs(z);
+    double re, im;
+    if (absz < 1e-4) {
+        // sinc interpolation kernel, gen_r_response with roffset = 0
+        const double r = PI * (numkern / 4.0) + (double) ii * (-PI / 2.0);
+        double s, c;
+        sincos(r, &s, &c);
+        const double sinc = (r == 0.0) ? 1.0 : s / r;
+        re = c * sinc;
+        im = s * sinc;
+        if (ii == numkern / 2) { // series value at the removable singularity
+            re = 1.0;
+            im = 0.0;
+        }
+    } else {
+        const double signz = z < 0.0 ? -1.0 : 1.0;
+        const double zd = signz * 1.4142135623730950488 / sqrt(absz);
+        const double cons = zd / 2.0;
+        const double pibyz = PI / z;
+        // the reference walks r by repeated addition of -0.5 from startr; every
+        // partial sum is exact in fp64 (multiples of 0.5), so this is the same r
+        const double r = (-0.5 * z + numkern / 4.0) - 0.5 * (double) ii;
+        const double yy = r * zd;
+        const double zz = yy + z * zd;
+        double s, c, sy, cy, sz, cz;
+        sincos(pibyz * r * r, &s, &c);
+        fresnel(yy, &sy, &cy);
+        fresnel(zz, &sz, &cz);
+        const double tr = signz * (cz - cy);
+        const double ti = sy - sz;
+        re = (tr * c - ti * s) * cons;
+        im = -(tr * s + ti * c) * cons;
+    }
+    const int half = numkern / 2;
+    const int pos = (ii >= half) ? (ii - half) : (fftlen - half + ii);
+    bank[(size_t) zi * fftlen + pos] = c32{(float) re, (float) im};
+}
+
+// In-place transform of each row of `data` (N points per row).
+template <class P, int DIR>
+__global__ __launch_bounds__(P::NT) void k_fft_rows(c32 *__restrict__ data,
+                                                   const c32 *__restrict__ tw1,
+                                                   const c32 *__restrict__ tw2)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    c32 *lds = reinterpret_cast<c32 *>(smem);
+    c32 *row = data + (size_t) blockIdx.x * P::N;
+    // all loads of the row happen in pass 1, all stores in pass 3, with
+    // barriers in between: in place is safe
+    afft::fft3<P, DIR>(
+        lds, tw1, tw2, [&](int, int a, int b) { return row[P::M1 * a + b]; },
+        [&](int n, c32 v) { row[n] = v; });
+}
+
+// ---------------------------------------------------------------------------
+// Block preparation.  One workgroup per block of the reference grid.
+//   window  : NF = fftlen/2 bins starting at lobin_b = rlo_b - halfwidth, zero
+//             outside the file (get_fourier_amplitudes)
+//   norm    : 1/sqrt(median(|d|^2 over the first numdata bins)/ln 2) in fp64,
+//             applied to those numdata bins only; bins beyond keep raw values
+//             exactly as the reference leaves them.  nph_norm > 0 replaces the
+//             median by the -photon constant.
+//   forward : NF-point FFT.  The reference zero-interleaves to fftlen points
+//             first; that transform is this one repeated twice, X'[k] = X[k mod NF].
+// The median is the exact order statistic (numdata-1)/2 (lower median), found
+// by a bitwise radix select on the IEEE bit patterns of the non-negative powers.
+// ---------------------------------------------------------------------------
+template <class P>
+__global__ __launch_bounds__(P::NT) void k_block_prep(
+    const c32 *__restrict__ fft, int64_t numbins, int64_t file_lobin,
+    const int64_t *__restrict__ blk_lobin, const int *__restrict__ blk_numdata,
+    c32 *__restrict__ blockfft, double nph_norm, const c32 *__restrict__ tw1,
+    const c32 *__restrict__ tw2)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    c32 *lds = reinterpret_cast<c32 *>(smem);
+    // wave partial counts live behind the FFT image (launch with LDS_BYTES + 64)
+    int (*s_cnt)[P::NT / 64] = reinterpret_cast<int (*)[P::NT / 64]>(smem + P::LDS_BYTES);
+    static_assert(P::B1 == 1, "block prep expects one pass-1 butterfly per thread");
+    static_assert(2 * (P::NT / 64) * 4 <= 64, "count scratch does not fit");
+
+    const int t = threadIdx.x;
+    const int blk = blockIdx.x;
+    const int64_t lobin = blk_lobin[blk];
+    const int numdata = blk_numdata[blk];
+
+    c32 d[P::R1];
+    uint32_t pw[P::R1];
+#pragma unroll
+    for (int a = 0; a < P::R1; a++) {
+        const int idx = P::M1 * a + t;
+        const int64_t fbin = lobin + idx - file_lobin;
+        c32 x = c32{0.f, 0.f};
+        if (fbin >= 0 && fbin < numbins)
+            x = fft[fbin];
+        d[a] = x;
+        // r*r + i*i with each operation rounded on its own (no fma), so the
+        // selected median is bit-identical to a plain C evaluation
+        const float p = __fadd_rn(__fmul_rn(x.x, x.x), __fmul_rn(x.y, x.y));
+        pw[a] = (idx < numdata) ? __float_as_uint(p) : 0xFFFFFFFFu;
+    }
+
+    double norm;
+    if (nph_norm > 0.0) {
+        norm = nph_norm;
+    } else {
+        const int k = (numdata - 1) / 2;
+        uint32_t prefix = 0;
+        int slot = 0;
+        for (int bit = 30; bit >= 0; bit--) {
+            const uint32_t cand = prefix | (1u << bit);
+            int c = 0;
+#pragma unroll
+            for (int a = 0; a < P::R1; a++)
+                c += (pw[a] < cand) ? 1 : 0;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+                c += __shfl_xor(c, off);
+            if ((t & 63) == 0)
+                s_cnt[slot][t >> 6] = c;
+            __syncthreads();
+            int total = 0;
+#pragma unroll
+            for (int w = 0; w < P::NT / 64; w++)
+                total += s_cnt[slot][w];
+            if (total <= k)
+                prefix = cand;
+            slot ^= 1; // the other slot is free: everyone passed the barrier after reading it
+        }
+        const double med = (double) __uint_as_float(prefix);
+        norm = 1.0 / sqrt(med / 0.69314718055994530942);
+    }
+#pragma unroll
+    for (int a = 0; a < P::R1; a++) {
+        const int idx = P::M1 * a + t;
+        if (idx < numdata) {
+            d[a].x = (float) ((double) d[a].x * norm);
+            d[a].y = (float) ((double) d[a].y * norm);
+        }
+    }
+    __syncthreads();
+    c32 *out = blockfft + (size_t) blk * P::N;
+    afft::fft3<P, -1>(
+        lds, tw1, tw2, [&](int, int a, int) { return d[a]; }, [&](int n, c32 v) { out[n] = v; });
+}
+
+// ---------------------------------------------------------------------------
+// Correlation: one workgroup per (template z, chunk of blocks).  The template's
+// spectrum stays in registers for the whole chunk.  For each block:
+//   X[k] = D[k mod N/2] * conj(K_z[k]);  x = IFFT_N(X) (unnormalised);
+//   plane[z][col_b + j] = |x[j + 2*halfwidth]|^2 / N^2,  0 <= j < ncols_b
+// ---------------------------------------------------------------------------
+template <class P, bool KEEPK>
+__global__ __launch_bounds__(P::NT, 2) void k_correlate(
+    const c32 *__restrict__ bank, const c32 *__restrict__ blockfft,
+    const int64_t *__restrict__ blk_col, const int *__restrict__ blk_ncols, int nblk, int chunk,
+    float *__restrict__ plane, int64_t rlen, int halfwidth, const c32 *__restrict__ tw1,
+    const c32 *__restrict__ tw2)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    c32 *lds = reinterpret_cast<c32 *>(smem);
+    static_assert(P::B1 == 1, "correlate expects one pass-1 butterfly per thread");
+    constexpr int NF = P::N / 2;
+    constexpr int H = P::R1 / 2; // M1 * H == NF: inputs a and a + H are the same bin
+
+    const int t = threadIdx.x;
+    const int z = blockIdx.x;
+    const int b0 = blockIdx.y * chunk;
+    const int b1 = min(b0 + chunk, nblk);
+
+    // KEEPK: the template's spectrum stays in registers for the whole chunk;
+    // otherwise it is re-read (from L2) for every block to save 2*R1 registers
+    const c32 *krow = bank + (size_t) z * P::N;
+    c32 kreg[KEEPK ? P::R1 : 1];
+    if constexpr (KEEPK) {
+#pragma unroll
+        for (int a = 0; a < P::R1; a++)
+            kreg[a] = krow[P::M1 * a + t];
+    }
+    const float norm = 1.0f / ((float) P::N * (float) P::N);
+    float *prow = plane + (size_t) z * (size_t) rlen;
+    const int shift = 2 * halfwidth;
+
+    for (int blk = b0; blk < b1; blk++) {
+        // The tables are loop-invariant; left alone the compiler hoists every
+        // load of them out of the block loop and runs out of registers.  Launder
+        // the pointers so each block re-reads them (L1/L2 hits).
+        const c32 *tw1_l = tw1, *tw2_l = tw2, *krow_l = krow;
+        asm volatile("" : "+s"(tw1_l), "+s"(tw2_l), "+s"(krow_l));
+        const c32 *D = blockfft + (size_t) blk * NF;
+        c32 dreg[H];
+#pragma unroll
+        for (int a = 0; a < H; a++)
+            dreg[a] = D[P::M1 * a + t];
+        float *out = prow + blk_col[blk];
+        const int ncols = blk_ncols[blk];
+        afft::fft3<P, +1>(
+            lds, tw1_l, tw2_l,
+            [&](int, int a, int) {
+                if constexpr (KEEPK)
+                    return afft::cmul_conj(dreg[a % H], kreg[a]);
+                else
+                    return afft::cmul_conj(dreg[a % H], krow_l[P::M1 * a + t]);
+            },
+            [&](int n, c32 v) {
+                const int j = n - shift;
+                if (j >= 0 && j < ncols)
+                    out[j] = (v.x * v.x + v.y * v.y) * norm;
+            });
+        __syncthreads(); // pass-3 reads done before the next block's pass-1 writes
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Harmonic sum + threshold.  One thread per fundamental column (absolute
+// half-bin index rind = col0 + c), looping over z rows.  For stage s >= 1 and
+// odd h < 2^s the sub-harmonic cell is
+//   row  ztab[harm][zi]                       (calc_required_z / index_from_z)
+//   col  (int)(rind * h / 2^s + 0.5) = (rind*h + 2^(s-1)) >> s   (exact: dyadic)
+// and the running float sum is accumulated in the reference's order
+// (fundamental, 1/2, 1/4, 3/4, 1/8, ...).  After each stage the sum is compared
+// with powcut[stage]; hits are compacted per wavefront with a ballot and one
+// atomic per wave.
+// DUMP: instead of thresholding, write the sums after stage `dump_stage`.
+// ---------------------------------------------------------------------------
+struct HarmParams {
+    float powcut[6];
+};
+
+template <int NSTAGES, bool DUMP>
+__global__ __launch_bounds__(256) void k_harmsum(
+    const float *__restrict__ plane, int64_t rlen, int numz, int64_t col0, int64_t ncols,
+    const int *__restrict__ ztab, HarmParams prm, DevHit *__restrict__ hits,
+    unsigned int *__restrict__ count, unsigned int max_hits, int zchunk, float *__restrict__ dump,
+    int dump_stage)
+{
+    constexpr int NH = (1 << (NSTAGES - 1)) - 1; // sub-harmonics summed in total
+    const int64_t c = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    const bool live = c < ncols;
+    const int64_t rind = col0 + (live ? c : 0);
+    const int z0 = blockIdx.y * zchunk;
+    const int z1 = min(z0 + zchunk, numz);
+
+    int64_t src[NH > 0 ? NH : 1];
+    {
+        int i = 0;
+#pragma unroll
+        for (int s = 1; s < NSTAGES; s++) {
+#pragma unroll
+            for (int h = 1; h < (1 << s); h += 2) {
+                src[i] = (rind * h + (1 << (s - 1))) >> s;
+                i++;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63;
+
+    for (int zi = z0; zi < z1; zi++) {
+        float p = plane[(size_t) zi * rlen + rind];
+        float v[NH > 0 ? NH : 1];
+#pragma unroll
+        for (int i = 0; i < NH; i++) {
+            const int zz = ztab[i * numz + zi];
+            v[i] = plane[(size_t) zz * rlen + src[i]];
+        }
+        int i = 0;
+#pragma unroll
+        for (int s = 0; s < NSTAGES; s++) {
+            if (s > 0) {
+#pragma unroll
+                for (int h = 1; h < (1 << s); h += 2) {
+                    p += v[i];
+                    i++;
+                }
+            }
+            if constexpr (DUMP) {
+                if (s == dump_stage && live)
+                    dump[(size_t) zi * ncols + c] = p;
+            } else {
+                const bool hit = live && (p > prm.powcut[s]);
+                const unsigned long long mask = __ballot(hit);
+                if (mask) {
+                    unsigned int base = 0;
+                    const int leader = __ffsll((long long) mask) - 1;
+                    if (lane == leader)
+                        base = atomicAdd(count, (unsigned int) __popcll(mask));
+                    base = __shfl(base, leader);
+                    if (hit) {
+                        const unsigned int pos =
+                            base + (unsigned int) __popcll(mask & ((1ull << lane) - 1ull));
+                        if (pos < max_hits)
+                            hits[pos] = DevHit{p, ((uint32_t) s << 16) | (uint32_t) zi, rind};
+                    }
+                }
+            }
+        }
+    }
+}
+
+} // namespace accelk

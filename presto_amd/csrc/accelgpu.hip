@@ -1,0 +1,966 @@
+// accelgpu.hip -- C ABI of libaccelgpu.so (see include/accelgpu.h).
+//
+// Data layout in HBM (one context = one search geometry at a time):
+//   fft       complex64[numbins]              the input spectrum (.fft layout)
+//   bank      complex64[numz][fftlen]         FFT'd z-response templates
+//   blockfft  complex64[nblk][fftlen/2]       forward FFT of each normalised block window
+//   plane     float[numz][rlen]               fundamental powers, rlen = 2*(highestbin+7470)
+//   hits      {float,u32,i64}[cap]            compacted threshold crossings
+// Blocks follow the reference grid: pre-population blocks at r = 8 + k*3735 below
+// rlo, search blocks at r = rlo + k*3735.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "accel_host.hpp"
+#include "accel_kernels.hpp"
+#include "accelgpu.h"
+
+using accelhost::set_error;
+using accelk::c32;
+using accelk::DevHit;
+
+namespace {
+
+typedef afft::Plan<16, 16, 16, 256> P4K;
+typedef afft::Plan<32, 16, 16, 256> P8K;
+typedef afft::Plan<32, 16, 32, 512> P16K;
+
+#define HIPCHK(expr)                                                                     \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,   \
+                      __LINE__);                                                         \
+            return ACCELGPU_ERR_HIP;                                                     \
+        }                                                                                \
+    } while (0)
+
+struct Twiddles {
+    c32 *tw1 = nullptr, *tw2 = nullptr;
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+} // namespace
+
+struct accelgpu_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+
+    // kernel bank
+    int zmax = -1, numz = 0, fftlen = 0, halfwidth = 0;
+    c32 *d_bank = nullptr;
+    Twiddles tw_inv, tw_fwd_full, tw_fwd_half;
+
+    // spectrum
+    const c32 *d_fft = nullptr;
+    c32 *d_fft_owned = nullptr;
+    size_t fft_cap = 0;
+    int64_t numbins = 0;
+
+    // search geometry
+    bool have_search = false;
+    accelgpu_setup setup{};
+    int norm_type = 0;
+    float nph = 0.f;
+    int nblk = 0, nprepop = 0, nsearch = 0;
+    int64_t col0 = 0, ncols = 0; // first search column (2*rlo) and number of search columns
+    int64_t *d_blk_lobin = nullptr, *d_blk_col = nullptr;
+    int *d_blk_numdata = nullptr, *d_blk_ncols = nullptr;
+    size_t blk_cap = 0;
+    c32 *d_blockfft = nullptr;
+    size_t blockfft_cap = 0;
+    float *d_plane = nullptr;
+    size_t plane_cap = 0;
+    int *d_ztab = nullptr;
+    size_t ztab_cap = 0;
+
+    // hits
+    DevHit *d_hits = nullptr;
+    DevHit *h_hits = nullptr; // pinned
+    unsigned int *d_count = nullptr, *h_count = nullptr;
+    size_t hits_cap = 0;
+    size_t prefetch_hits = 0; // hits copied back speculatively by run_launch
+    bool launched = false;
+
+    // scratch for the single-block getters
+    float *d_tmp = nullptr;
+    size_t tmp_cap = 0;
+    int64_t *d_one_lobin = nullptr, *d_one_col = nullptr;
+    int *d_one_numdata = nullptr, *d_one_ncols = nullptr;
+    c32 *d_one_blockfft = nullptr;
+
+    // profiling
+    bool profiling = false;
+    std::vector<EventPair> ev[3];
+    std::vector<EventPair> ev_pool;
+    int64_t prof_launches[3] = {0, 0, 0};
+    double prof_ms[3] = {0, 0, 0};
+};
+
+namespace {
+
+int use(accelgpu_ctx *ctx)
+{
+    if (!ctx) {
+        set_error("null context");
+        return ACCELGPU_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    return ACCELGPU_OK;
+}
+
+template <class T> int dev_reserve(T **p, size_t *cap, size_t want, bool zero, hipStream_t st)
+{
+    if (*cap >= want && *p)
+        return ACCELGPU_OK;
+    if (*p)
+        HIPCHK(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    hipError_t e = hipMalloc((void **) p, want * sizeof(T));
+    if (e != hipSuccess) {
+        set_error("hipMalloc of %zu bytes failed: %s", want * sizeof(T), hipGetErrorString(e));
+        return ACCELGPU_ERR_NOMEM;
+    }
+    *cap = want;
+    if (zero)
+        HIPCHK(hipMemsetAsync(*p, 0, want * sizeof(T), st));
+    return ACCELGPU_OK;
+}
+
+template <class P> int make_twiddles(Twiddles *tw, int dir, hipStream_t st)
+{
+    std::vector<c32> t1((size_t) P::R1 * P::M1), t2((size_t) P::R2 * P::R3);
+    for (int n1 = 0; n1 < P::R1; n1++)
+        for (int b = 0; b < P::M1; b++) {
+            const double a = dir * 2.0 * M_PI * (double) ((long long) b * n1 % P::N) / (double) P::N;
+            t1[(size_t) n1 * P::M1 + b] = c32{(float) std::cos(a), (float) std::sin(a)};
+        }
+    for (int e = 0; e < P::R2; e++)
+        for (int d = 0; d < P::R3; d++) {
+            const double a = dir * 2.0 * M_PI * (double) (e * d % P::M1) / (double) P::M1;
+            t2[(size_t) e * P::R3 + d] = c32{(float) std::cos(a), (float) std::sin(a)};
+        }
+    if (tw->tw1) HIPCHK(hipFree(tw->tw1));
+    if (tw->tw2) HIPCHK(hipFree(tw->tw2));
+    HIPCHK(hipMalloc((void **) &tw->tw1, t1.size() * sizeof(c32)));
+    HIPCHK(hipMalloc((void **) &tw->tw2, t2.size() * sizeof(c32)));
+    HIPCHK(hipMemcpyAsync(tw->tw1, t1.data(), t1.size() * sizeof(c32), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(tw->tw2, t2.data(), t2.size() * sizeof(c32), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st)); // host vectors die at return
+    return ACCELGPU_OK;
+}
+
+template <class K> int allow_lds(K kernel, int bytes)
+{
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return ACCELGPU_OK;
+}
+
+int prof_begin(accelgpu_ctx *ctx, int which, EventPair *ep)
+{
+    if (!ctx->profiling)
+        return ACCELGPU_OK;
+    if (!ctx->ev_pool.empty()) {
+        *ep = ctx->ev_pool.back();
+        ctx->ev_pool.pop_back();
+    } else {
+        HIPCHK(hipEventCreate(&ep->a));
+        HIPCHK(hipEventCreate(&ep->b));
+    }
+    HIPCHK(hipEventRecord(ep->a, ctx->stream));
+    (void) which;
+    return ACCELGPU_OK;
+}
+
+int prof_end(accelgpu_ctx *ctx, int which, EventPair *ep)
+{
+    if (!ctx->profiling)
+        return ACCELGPU_OK;
+    HIPCHK(hipEventRecord(ep->b, ctx->stream));
+    ctx->ev[which].push_back(*ep);
+    return ACCELGPU_OK;
+}
+
+// Block descriptors exactly as subharm_ffdot_plane() derives them for
+// numharm = harmnum = 1 (reference src/accel_utils.c:903-907, 929-934).
+struct BlockDesc {
+    int rlo;
+    int64_t lobin;
+    int numdata;
+};
+
+BlockDesc describe_block(double startr, int halfwidth)
+{
+    const double fullrhi = startr + ACCELGPU_USELEN * 0.5 - 0.5;
+    const double drlo = accelhost::calc_required_r(1.0, startr);
+    const double drhi = accelhost::calc_required_r(1.0, fullrhi);
+    BlockDesc d;
+    d.rlo = (int) std::floor(drlo);
+    d.lobin = (int64_t) d.rlo - halfwidth;
+    const int hibin = (int) std::ceil(drhi) + halfwidth;
+    d.numdata = (int) (hibin - d.lobin + 1);
+    return d;
+}
+
+int launch_block_prep(accelgpu_ctx *ctx, int nblk, const int64_t *d_lobin, const int *d_numdata,
+                      c32 *d_out)
+{
+    const double nph_norm = ctx->nph > 0.f ? 1.0 / std::sqrt((double) ctx->nph) : 0.0;
+    EventPair ep;
+    int rc = prof_begin(ctx, 0, &ep);
+    if (rc) return rc;
+    if (ctx->fftlen == 8192) {
+        hipLaunchKernelGGL(accelk::k_block_prep<P4K>, dim3(nblk), dim3(P4K::NT),
+                           P4K::LDS_BYTES + 64, ctx->stream, ctx->d_fft, ctx->numbins,
+                           ctx->setup.lobin, d_lobin, d_numdata, d_out, nph_norm,
+                           ctx->tw_fwd_half.tw1, ctx->tw_fwd_half.tw2);
+    } else {
+        hipLaunchKernelGGL(accelk::k_block_prep<P8K>, dim3(nblk), dim3(P8K::NT),
+                           P8K::LDS_BYTES + 64, ctx->stream, ctx->d_fft, ctx->numbins,
+                           ctx->setup.lobin, d_lobin, d_numdata, d_out, nph_norm,
+                           ctx->tw_fwd_half.tw1, ctx->tw_fwd_half.tw2);
+    }
+    HIPCHK(hipGetLastError());
+    return prof_end(ctx, 0, &ep);
+}
+
+int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const int64_t *d_col,
+                     const int *d_ncols, float *d_plane, int64_t rlen)
+{
+    const int chunk = 8;
+    const dim3 grid(ctx->numz, (nblk + chunk - 1) / chunk);
+    EventPair ep;
+    int rc = prof_begin(ctx, 1, &ep);
+    if (rc) return rc;
+    if (ctx->fftlen == 8192) {
+        hipLaunchKernelGGL((accelk::k_correlate<P8K, false>), grid, dim3(P8K::NT), P8K::LDS_BYTES,
+                           ctx->stream, ctx->d_bank, d_blockfft, d_col, d_ncols, nblk, chunk,
+                           d_plane, rlen, ctx->halfwidth, ctx->tw_inv.tw1, ctx->tw_inv.tw2);
+    } else {
+        hipLaunchKernelGGL((accelk::k_correlate<P16K, false>), grid, dim3(P16K::NT), P16K::LDS_BYTES,
+                           ctx->stream, ctx->d_bank, d_blockfft, d_col, d_ncols, nblk, chunk,
+                           d_plane, rlen, ctx->halfwidth, ctx->tw_inv.tw1, ctx->tw_inv.tw2);
+    }
+    HIPCHK(hipGetLastError());
+    return prof_end(ctx, 1, &ep);
+}
+
+template <bool DUMP>
+int launch_harmsum(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, float *dump,
+                   int dump_stage)
+{
+    accelk::HarmParams prm;
+    for (int i = 0; i < 6; i++)
+        prm.powcut[i] = i < ctx->setup.numharmstages ? ctx->setup.powcut[i] : INFINITY;
+    const int numz = ctx->numz;
+    const int zchunk = numz; // one workgroup walks every z row of its 256 columns
+    const dim3 grid((unsigned) ((ncols + 255) / 256), (numz + zchunk - 1) / zchunk);
+    const unsigned int cap = (unsigned int) std::min<size_t>(ctx->hits_cap, 0xFFFFFFFFu);
+    EventPair ep;
+    if (!DUMP) {
+        int rc = prof_begin(ctx, 2, &ep);
+        if (rc) return rc;
+    }
+#define LAUNCH_HS(NS)                                                                        \
+    hipLaunchKernelGGL((accelk::k_harmsum<NS, DUMP>), grid, dim3(256), 0, ctx->stream,       \
+                       ctx->d_plane, ctx->setup.rlen, numz, col0, ncols, ctx->d_ztab, prm,    \
+                       ctx->d_hits, ctx->d_count, cap, zchunk, dump, dump_stage)
+    switch (nstages) {
+    case 1: LAUNCH_HS(1); break;
+    case 2: LAUNCH_HS(2); break;
+    case 3: LAUNCH_HS(3); break;
+    case 4: LAUNCH_HS(4); break;
+    case 5: LAUNCH_HS(5); break;
+    case 6: LAUNCH_HS(6); break;
+    default:
+        set_error("bad number of harmonic stages %d", nstages);
+        return ACCELGPU_ERR_ARG;
+    }
+#undef LAUNCH_HS
+    HIPCHK(hipGetLastError());
+    if (!DUMP)
+        return prof_end(ctx, 2, &ep);
+    return ACCELGPU_OK;
+}
+
+int reserve_hits(accelgpu_ctx *ctx, size_t want)
+{
+    if (ctx->hits_cap >= want)
+        return ACCELGPU_OK;
+    if (ctx->d_hits) HIPCHK(hipFree(ctx->d_hits));
+    if (ctx->h_hits) HIPCHK(hipHostFree(ctx->h_hits));
+    ctx->d_hits = nullptr;
+    ctx->h_hits = nullptr;
+    ctx->hits_cap = 0;
+    if (hipMalloc((void **) &ctx->d_hits, want * sizeof(DevHit)) != hipSuccess ||
+        hipHostMalloc((void **) &ctx->h_hits, want * sizeof(DevHit)) != hipSuccess) {
+        set_error("cannot allocate room for %zu hits", want);
+        return ACCELGPU_ERR_NOMEM;
+    }
+    ctx->hits_cap = want;
+    return ACCELGPU_OK;
+}
+
+int check_ready(accelgpu_ctx *ctx, bool need_fft)
+{
+    if (ctx->zmax < 0) {
+        set_error("accelgpu_build_kernels() has not been called");
+        return ACCELGPU_ERR_ARG;
+    }
+    if (!ctx->have_search) {
+        set_error("accelgpu_set_search() has not been called");
+        return ACCELGPU_ERR_ARG;
+    }
+    if (need_fft && !ctx->d_fft) {
+        set_error("no spectrum loaded (accelgpu_load_fft)");
+        return ACCELGPU_ERR_ARG;
+    }
+    if (ctx->setup.zmax != ctx->zmax) {
+        set_error("kernel bank built for zmax=%d but the search uses zmax=%d", ctx->zmax,
+                  ctx->setup.zmax);
+        return ACCELGPU_ERR_ARG;
+    }
+    return ACCELGPU_OK;
+}
+
+int queue_fill(accelgpu_ctx *ctx)
+{
+    int rc = launch_block_prep(ctx, ctx->nblk, ctx->d_blk_lobin, ctx->d_blk_numdata, ctx->d_blockfft);
+    if (rc) return rc;
+    return launch_correlate(ctx, ctx->nblk, ctx->d_blockfft, ctx->d_blk_col, ctx->d_blk_ncols,
+                            ctx->d_plane, ctx->setup.rlen);
+}
+
+int queue_search(accelgpu_ctx *ctx)
+{
+    HIPCHK(hipMemsetAsync(ctx->d_count, 0, sizeof(unsigned int), ctx->stream));
+    int rc = launch_harmsum<false>(ctx, ctx->setup.numharmstages, ctx->col0, ctx->ncols, nullptr, 0);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->h_count, ctx->d_count, sizeof(unsigned int), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    return ACCELGPU_OK;
+}
+
+// Waits for the queued search, re-running it with a larger buffer if the
+// compaction overflowed, then sorts into the reference's visiting order.
+int finish_search(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits, int64_t *n_hits)
+{
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    size_t n = *ctx->h_count;
+    size_t have = ctx->prefetch_hits;
+    ctx->prefetch_hits = 0;
+    if (n > ctx->hits_cap) {
+        int rc = reserve_hits(ctx, n + n / 4 + 1024);
+        if (rc) return rc;
+        rc = queue_search(ctx);
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        n = *ctx->h_count;
+        have = 0;
+        if (n > ctx->hits_cap) {
+            set_error("hit count changed between two runs of the same search");
+            return ACCELGPU_ERR_HIP;
+        }
+    }
+    if (n > have) {
+        HIPCHK(hipMemcpyAsync(ctx->h_hits + have, ctx->d_hits + have, (n - have) * sizeof(DevHit),
+                              hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    *n_hits = (int64_t) n;
+    if ((int64_t) n > max_hits) {
+        set_error("%zu hits but room for %lld: re-run with a larger buffer", n, (long long) max_hits);
+        return ACCELGPU_ERR_OVERFLOW;
+    }
+    const int64_t col0 = ctx->col0;
+    for (size_t i = 0; i < n; i++) {
+        const DevHit &d = ctx->h_hits[i];
+        accelgpu_hit &h = hits[i];
+        h.power = d.power;
+        h.stage = (int32_t) (d.stage_zind >> 16);
+        h.zind = (int32_t) (d.stage_zind & 0xFFFF);
+        h.rind = d.rind;
+        h.block = (int32_t) ((d.rind - col0) / ACCELGPU_USELEN);
+    }
+    std::sort(hits, hits + n, [](const accelgpu_hit &a, const accelgpu_hit &b) {
+        if (a.block != b.block) return a.block < b.block;
+        if (a.stage != b.stage) return a.stage < b.stage;
+        if (a.zind != b.zind) return a.zind < b.zind;
+        return a.rind < b.rind;
+    });
+    return ACCELGPU_OK;
+}
+
+} // namespace
+
+// ===========================================================================
+extern "C" {
+
+const char *accelgpu_last_error(void) { return accelhost::last_error(); }
+const char *accelgpu_version(void) { return "accelgpu 0.1 (gfx950)"; }
+
+int accelgpu_z_resp_halfwidth(double z) { return accelhost::z_resp_halfwidth(z); }
+int accelgpu_calc_fftlen(int numharm, int harmnum, int max_zfull)
+{
+    return accelhost::calc_fftlen(numharm, harmnum, max_zfull);
+}
+double accelgpu_candidate_sigma(double power, int numsum, double numtrials)
+{
+    return accelhost::candidate_sigma(power, numsum, numtrials);
+}
+double accelgpu_power_for_sigma(double sigma, int numsum, double numtrials)
+{
+    return accelhost::power_for_sigma(sigma, numsum, numtrials);
+}
+int accelgpu_plan(int64_t numbins, int64_t N, double dt, int zmax, int numharm, double sigma,
+                  double flo, double fhi, int64_t lobin, accelgpu_setup *out)
+{
+    if (!out) {
+        set_error("accelgpu_plan: null output");
+        return ACCELGPU_ERR_ARG;
+    }
+    return accelhost::plan(numbins, N, dt, zmax, numharm, sigma, flo, fhi, lobin, out);
+}
+int accelgpu_replay_candidates(const accelgpu_setup *setup, const accelgpu_hit *hits,
+                               int64_t n_hits, accelgpu_cand *cands, int64_t max_cands,
+                               int64_t *n_cands, float *sigma_out, int32_t *added)
+{
+    if (!setup || (!hits && n_hits > 0) || !n_cands || (!cands && max_cands > 0)) {
+        set_error("accelgpu_replay_candidates: null argument");
+        return ACCELGPU_ERR_ARG;
+    }
+    return accelhost::replay(setup, hits, n_hits, cands, max_cands, n_cands, sigma_out, added);
+}
+
+int accelgpu_create(accelgpu_ctx **out, int device)
+{
+    if (!out) {
+        set_error("accelgpu_create: null output");
+        return ACCELGPU_ERR_ARG;
+    }
+    *out = nullptr;
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) {
+        set_error("accelgpu_create: device %d of %d", device, ndev);
+        return ACCELGPU_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(device));
+    accelgpu_ctx *ctx = new accelgpu_ctx();
+    ctx->device = device;
+    HIPCHK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    HIPCHK(hipMalloc((void **) &ctx->d_count, sizeof(unsigned int)));
+    HIPCHK(hipHostMalloc((void **) &ctx->h_count, sizeof(unsigned int)));
+    HIPCHK(hipMalloc((void **) &ctx->d_one_lobin, sizeof(int64_t)));
+    HIPCHK(hipMalloc((void **) &ctx->d_one_col, sizeof(int64_t)));
+    HIPCHK(hipMalloc((void **) &ctx->d_one_numdata, sizeof(int)));
+    HIPCHK(hipMalloc((void **) &ctx->d_one_ncols, sizeof(int)));
+    int rc;
+    if ((rc = allow_lds(accelk::k_block_prep<P4K>, P4K::LDS_BYTES + 64))) return rc;
+    if ((rc = allow_lds(accelk::k_block_prep<P8K>, P8K::LDS_BYTES + 64))) return rc;
+    if ((rc = allow_lds(accelk::k_correlate<P8K, false>, P8K::LDS_BYTES))) return rc;
+    if ((rc = allow_lds(accelk::k_correlate<P16K, false>, P16K::LDS_BYTES))) return rc;
+    if ((rc = allow_lds(accelk::k_fft_rows<P8K, -1>, P8K::LDS_BYTES))) return rc;
+    if ((rc = allow_lds(accelk::k_fft_rows<P16K, -1>, P16K::LDS_BYTES))) return rc;
+    if ((rc = reserve_hits(ctx, (size_t) 1 << 20))) return rc;
+    *out = ctx;
+    return ACCELGPU_OK;
+}
+
+void accelgpu_destroy(accelgpu_ctx *ctx)
+{
+    if (!ctx)
+        return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &v : ctx->ev)
+        for (auto &e : v) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    for (auto &e : ctx->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    void *dev[] = {ctx->d_bank, ctx->tw_inv.tw1, ctx->tw_inv.tw2, ctx->tw_fwd_full.tw1,
+                   ctx->tw_fwd_full.tw2, ctx->tw_fwd_half.tw1, ctx->tw_fwd_half.tw2,
+                   ctx->d_fft_owned, ctx->d_blk_lobin, ctx->d_blk_col, ctx->d_blk_numdata,
+                   ctx->d_blk_ncols, ctx->d_blockfft, ctx->d_plane, ctx->d_ztab, ctx->d_hits,
+                   ctx->d_count, ctx->d_tmp, ctx->d_one_lobin, ctx->d_one_col,
+                   ctx->d_one_numdata, ctx->d_one_ncols, ctx->d_one_blockfft};
+    for (void *p : dev)
+        if (p) hipFree(p);
+    if (ctx->h_hits) hipHostFree(ctx->h_hits);
+    if (ctx->h_count) hipHostFree(ctx->h_count);
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int accelgpu_set_stream(accelgpu_ctx *ctx, void *hip_stream)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t) hip_stream : ctx->own_stream;
+    return ACCELGPU_OK;
+}
+
+int accelgpu_synchronize(accelgpu_ctx *ctx)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ACCELGPU_OK;
+}
+
+int accelgpu_build_kernels(accelgpu_ctx *ctx, int zmax)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if (zmax < 0 || zmax > 1200) {
+        set_error("accelgpu_build_kernels: zmax %d outside 0..1200", zmax);
+        return ACCELGPU_ERR_ARG;
+    }
+    if (zmax % 2)
+        zmax = (zmax / 2 + 1) * 2;
+    if (zmax == ctx->zmax)
+        return ACCELGPU_OK;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const int numz = (zmax / 2) * 2 + 1;
+    const int fftlen = accelhost::calc_fftlen(1, 1, zmax);
+    if (fftlen != 8192 && fftlen != 16384) {
+        set_error("unsupported FFT length %d", fftlen);
+        return ACCELGPU_ERR_ARG;
+    }
+    if (fftlen != ctx->fftlen) {
+        if (fftlen == 8192) {
+            if ((rc = make_twiddles<P8K>(&ctx->tw_inv, +1, ctx->stream))) return rc;
+            if ((rc = make_twiddles<P8K>(&ctx->tw_fwd_full, -1, ctx->stream))) return rc;
+            if ((rc = make_twiddles<P4K>(&ctx->tw_fwd_half, -1, ctx->stream))) return rc;
+        } else {
+            if ((rc = make_twiddles<P16K>(&ctx->tw_inv, +1, ctx->stream))) return rc;
+            if ((rc = make_twiddles<P16K>(&ctx->tw_fwd_full, -1, ctx->stream))) return rc;
+            if ((rc = make_twiddles<P8K>(&ctx->tw_fwd_half, -1, ctx->stream))) return rc;
+        }
+    }
+    std::vector<int> hw(numz);
+    int maxhw = 0;
+    for (int i = 0; i < numz; i++) {
+        hw[i] = accelhost::z_resp_halfwidth((double) (-zmax + 2 * i));
+        maxhw = std::max(maxhw, hw[i]);
+    }
+    if (ctx->d_bank) HIPCHK(hipFree(ctx->d_bank));
+    ctx->d_bank = nullptr;
+    const size_t bank_elems = (size_t) numz * fftlen;
+    if (hipMalloc((void **) &ctx->d_bank, bank_elems * sizeof(c32)) != hipSuccess) {
+        set_error("cannot allocate the kernel bank (%zu bytes)", bank_elems * sizeof(c32));
+        return ACCELGPU_ERR_NOMEM;
+    }
+    int *d_hw = nullptr;
+    HIPCHK(hipMalloc((void **) &d_hw, numz * sizeof(int)));
+    HIPCHK(hipMemcpyAsync(d_hw, hw.data(), numz * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_bank, 0, bank_elems * sizeof(c32), ctx->stream));
+    const int maxkern = 4 * maxhw;
+    hipLaunchKernelGGL(accelk::k_gen_zresp, dim3((maxkern + 127) / 128, numz), dim3(128), 0,
+                       ctx->stream, ctx->d_bank, d_hw, zmax, fftlen, maxkern);
+    HIPCHK(hipGetLastError());
+    if (fftlen == 8192)
+        hipLaunchKernelGGL((accelk::k_fft_rows<P8K, -1>), dim3(numz), dim3(P8K::NT),
+                           P8K::LDS_BYTES, ctx->stream, ctx->d_bank, ctx->tw_fwd_full.tw1,
+                           ctx->tw_fwd_full.tw2);
+    else
+        hipLaunchKernelGGL((accelk::k_fft_rows<P16K, -1>), dim3(numz), dim3(P16K::NT),
+                           P16K::LDS_BYTES, ctx->stream, ctx->d_bank, ctx->tw_fwd_full.tw1,
+                           ctx->tw_fwd_full.tw2);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(d_hw));
+    ctx->zmax = zmax;
+    ctx->numz = numz;
+    ctx->fftlen = fftlen;
+    ctx->halfwidth = hw[0];
+    return ACCELGPU_OK;
+}
+
+int accelgpu_get_kernel(accelgpu_ctx *ctx, int zind, float *out)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if (ctx->zmax < 0 || zind < 0 || zind >= ctx->numz || !out) {
+        set_error("accelgpu_get_kernel: no bank or zind %d out of range", zind);
+        return ACCELGPU_ERR_ARG;
+    }
+    HIPCHK(hipMemcpyAsync(out, ctx->d_bank + (size_t) zind * ctx->fftlen,
+                          (size_t) ctx->fftlen * sizeof(c32), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ACCELGPU_OK;
+}
+
+int accelgpu_load_fft(accelgpu_ctx *ctx, const float *host, int64_t numbins)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if (!host || numbins <= 0) {
+        set_error("accelgpu_load_fft: null spectrum or numbins <= 0");
+        return ACCELGPU_ERR_ARG;
+    }
+    if ((rc = dev_reserve(&ctx->d_fft_owned, &ctx->fft_cap, (size_t) numbins, false, ctx->stream)))
+        return rc;
+    HIPCHK(hipMemcpyAsync(ctx->d_fft_owned, host, (size_t) numbins * sizeof(c32),
+                          hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream)); // the caller may free `host` on return
+    ctx->d_fft = ctx->d_fft_owned;
+    ctx->numbins = numbins;
+    return ACCELGPU_OK;
+}
+
+int accelgpu_load_fft_device(accelgpu_ctx *ctx, const void *dev, int64_t numbins)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if (!dev || numbins <= 0) {
+        set_error("accelgpu_load_fft_device: null spectrum or numbins <= 0");
+        return ACCELGPU_ERR_ARG;
+    }
+    ctx->d_fft = (const c32 *) dev;
+    ctx->numbins = numbins;
+    return ACCELGPU_OK;
+}
+
+int accelgpu_set_search(accelgpu_ctx *ctx, const accelgpu_setup *s, int norm_type, float nph)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if (!s) {
+        set_error("accelgpu_set_search: null setup");
+        return ACCELGPU_ERR_ARG;
+    }
+    if (ctx->zmax < 0 || s->zmax != ctx->zmax) {
+        set_error("accelgpu_set_search: build the kernel bank for zmax=%d first", s->zmax);
+        return ACCELGPU_ERR_ARG;
+    }
+    if (norm_type != 0) {
+        set_error("accelgpu_set_search: only block-median (0) and -photon normalisation are implemented");
+        return ACCELGPU_ERR_ARG;
+    }
+    if (s->numharmstages < 1 || s->numharmstages > ACCELGPU_MAXSTAGES || s->rlo < 0 ||
+        s->highestbin < s->rlo) {
+        set_error("accelgpu_set_search: inconsistent setup");
+        return ACCELGPU_ERR_ARG;
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const bool same_geometry = ctx->have_search && ctx->setup.rlo == s->rlo &&
+                               ctx->setup.highestbin == s->highestbin &&
+                               ctx->setup.lobin == s->lobin && ctx->setup.zmax == s->zmax;
+    ctx->setup = *s;
+    ctx->setup.numz = ctx->numz;
+    ctx->setup.fftlen = ctx->fftlen;
+    ctx->setup.halfwidth = ctx->halfwidth;
+    ctx->setup.rlen = (s->highestbin + ACCELGPU_USELEN) * 2;
+    ctx->setup.plane_bytes = ctx->setup.rlen * (int64_t) ctx->numz * 4;
+    ctx->norm_type = norm_type;
+    ctx->nph = nph;
+
+    // block grid (reference src/accelsearch.c:143-161 and 165-218)
+    std::vector<int64_t> lobin, col;
+    std::vector<int> numdata, ncols;
+    const double step = ACCELGPU_USELEN * 0.5;
+    const int64_t search_col0 = (int64_t) std::floor(accelhost::calc_required_r(1.0, s->rlo)) * 2;
+    int nprepop = 0, nsearch = 0;
+    for (double r = 8; r < s->rlo; r += step) {
+        const BlockDesc d = describe_block(r, ctx->halfwidth);
+        lobin.push_back(d.lobin);
+        numdata.push_back(d.numdata);
+        col.push_back((int64_t) d.rlo * 2);
+        // columns at or above the first search column belong to the search blocks
+        ncols.push_back((int) std::max<int64_t>(
+            0, std::min<int64_t>(ACCELGPU_USELEN, search_col0 - (int64_t) d.rlo * 2)));
+        nprepop++;
+    }
+    for (double r = s->rlo; r + step < (double) s->highestbin; r += step) {
+        const BlockDesc d = describe_block(r, ctx->halfwidth);
+        lobin.push_back(d.lobin);
+        numdata.push_back(d.numdata);
+        col.push_back((int64_t) d.rlo * 2);
+        ncols.push_back(ACCELGPU_USELEN);
+        nsearch++;
+    }
+    const int nblk = nprepop + nsearch;
+    for (int i = 0; i < nblk; i++)
+        if (numdata[i] > ctx->fftlen / 2) {
+            set_error("block window of %d bins exceeds fftlen/2 = %d", numdata[i], ctx->fftlen / 2);
+            return ACCELGPU_ERR_ARG;
+        }
+    ctx->nblk = nblk;
+    ctx->nprepop = nprepop;
+    ctx->nsearch = nsearch;
+    ctx->setup.num_prepop_blocks = nprepop;
+    ctx->setup.num_search_blocks = nsearch;
+    ctx->col0 = search_col0;
+    ctx->ncols = (int64_t) nsearch * ACCELGPU_USELEN;
+
+    if (nblk > 0) {
+        const size_t want = (size_t) nblk;
+        if (ctx->blk_cap < want) {
+            for (void *p : {(void *) ctx->d_blk_lobin, (void *) ctx->d_blk_col,
+                            (void *) ctx->d_blk_numdata, (void *) ctx->d_blk_ncols})
+                if (p) HIPCHK(hipFree(p));
+            ctx->d_blk_lobin = ctx->d_blk_col = nullptr;
+            ctx->d_blk_numdata = ctx->d_blk_ncols = nullptr;
+            HIPCHK(hipMalloc((void **) &ctx->d_blk_lobin, want * sizeof(int64_t)));
+            HIPCHK(hipMalloc((void **) &ctx->d_blk_col, want * sizeof(int64_t)));
+            HIPCHK(hipMalloc((void **) &ctx->d_blk_numdata, want * sizeof(int)));
+            HIPCHK(hipMalloc((void **) &ctx->d_blk_ncols, want * sizeof(int)));
+            ctx->blk_cap = want;
+        }
+        HIPCHK(hipMemcpy(ctx->d_blk_lobin, lobin.data(), want * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ctx->d_blk_col, col.data(), want * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ctx->d_blk_numdata, numdata.data(), want * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ctx->d_blk_ncols, ncols.data(), want * sizeof(int), hipMemcpyHostToDevice));
+        if ((rc = dev_reserve(&ctx->d_blockfft, &ctx->blockfft_cap,
+                              (size_t) nblk * (ctx->fftlen / 2), false, ctx->stream)))
+            return rc;
+    }
+
+    // the plane: zero-filled so that cells below r = 8, which nothing writes, read as 0
+    const size_t plane_elems = (size_t) ctx->setup.rlen * ctx->numz;
+    const bool fresh = ctx->plane_cap < plane_elems || !ctx->d_plane;
+    if ((rc = dev_reserve(&ctx->d_plane, &ctx->plane_cap, plane_elems, false, ctx->stream)))
+        return rc;
+    if (fresh || !same_geometry)
+        HIPCHK(hipMemsetAsync(ctx->d_plane, 0, plane_elems * sizeof(float), ctx->stream));
+
+    // sub-harmonic row table, in summing order (stage ascending, odd harmonic ascending)
+    const int nh = (1 << (s->numharmstages - 1)) - 1;
+    if (nh > 0) {
+        std::vector<int> ztab((size_t) nh * ctx->numz);
+        int i = 0;
+        for (int st = 1; st < s->numharmstages; st++)
+            for (int h = 1; h < (1 << st); h += 2, i++) {
+                const double f = (double) h / (double) (1 << st);
+                for (int zi = 0; zi < ctx->numz; zi++) {
+                    const int zz = (int) s->zlo + zi * 2;
+                    const int subz = accelhost::calc_required_z(f, zz);
+                    ztab[(size_t) i * ctx->numz + zi] = accelhost::index_from_z(subz, s->zlo);
+                }
+            }
+        if ((rc = dev_reserve(&ctx->d_ztab, &ctx->ztab_cap, ztab.size(), false, ctx->stream)))
+            return rc;
+        HIPCHK(hipMemcpy(ctx->d_ztab, ztab.data(), ztab.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->have_search = true;
+    ctx->launched = false;
+    return ACCELGPU_OK;
+}
+
+int accelgpu_fill_plane(accelgpu_ctx *ctx)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if ((rc = check_ready(ctx, true))) return rc;
+    if (ctx->nblk == 0)
+        return ACCELGPU_OK;
+    if ((rc = queue_fill(ctx))) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ACCELGPU_OK;
+}
+
+int accelgpu_search_plane(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits, int64_t *n_hits)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if ((rc = check_ready(ctx, false))) return rc;
+    if (!n_hits || (!hits && max_hits > 0)) {
+        set_error("accelgpu_search_plane: null output");
+        return ACCELGPU_ERR_ARG;
+    }
+    *n_hits = 0;
+    if (ctx->nsearch == 0)
+        return ACCELGPU_OK;
+    if ((rc = queue_search(ctx))) return rc;
+    return finish_search(ctx, hits, max_hits, n_hits);
+}
+
+int accelgpu_run_launch(accelgpu_ctx *ctx)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if ((rc = check_ready(ctx, true))) return rc;
+    if (ctx->launched) {
+        set_error("accelgpu_run_launch: previous launch has not been collected");
+        return ACCELGPU_ERR_ARG;
+    }
+    ctx->prefetch_hits = 0;
+    if (ctx->nsearch > 0) {
+        if ((rc = queue_fill(ctx))) return rc;
+        if ((rc = queue_search(ctx))) return rc;
+        // speculative copy of the head of the hit buffer: usually all of them
+        const size_t pre = std::min<size_t>(ctx->hits_cap, 65536);
+        HIPCHK(hipMemcpyAsync(ctx->h_hits, ctx->d_hits, pre * sizeof(DevHit), hipMemcpyDeviceToHost,
+                              ctx->stream));
+        ctx->prefetch_hits = pre;
+    }
+    ctx->launched = true;
+    return ACCELGPU_OK;
+}
+
+int accelgpu_run_collect(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits, int64_t *n_hits)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if (!ctx->launched) {
+        set_error("accelgpu_run_collect: nothing launched");
+        return ACCELGPU_ERR_ARG;
+    }
+    if (!n_hits || (!hits && max_hits > 0)) {
+        set_error("accelgpu_run_collect: null output");
+        return ACCELGPU_ERR_ARG;
+    }
+    ctx->launched = false;
+    *n_hits = 0;
+    if (ctx->nsearch == 0)
+        return ACCELGPU_OK;
+    size_t pre = ctx->prefetch_hits;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->prefetch_hits = std::min<size_t>(pre, *ctx->h_count);
+    return finish_search(ctx, hits, max_hits, n_hits);
+}
+
+int accelgpu_run(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits, int64_t *n_hits)
+{
+    int rc = accelgpu_run_launch(ctx);
+    if (rc) return rc;
+    return accelgpu_run_collect(ctx, hits, max_hits, n_hits);
+}
+
+int accelgpu_fund_block(accelgpu_ctx *ctx, double startr, float *powers, int32_t *rlo_out)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if ((rc = check_ready(ctx, true))) return rc;
+    if (!powers) {
+        set_error("accelgpu_fund_block: null output");
+        return ACCELGPU_ERR_ARG;
+    }
+    const BlockDesc d = describe_block(startr, ctx->halfwidth);
+    const int64_t zero = 0;
+    const int ncols = ACCELGPU_USELEN;
+    const size_t elems = (size_t) ctx->numz * ACCELGPU_USELEN;
+    if ((rc = dev_reserve(&ctx->d_tmp, &ctx->tmp_cap, elems, false, ctx->stream))) return rc;
+    if (!ctx->d_one_blockfft)
+        HIPCHK(hipMalloc((void **) &ctx->d_one_blockfft, (size_t) 8192 * sizeof(c32)));
+    HIPCHK(hipMemcpyAsync(ctx->d_one_lobin, &d.lobin, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_one_numdata, &d.numdata, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_one_col, &zero, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_one_ncols, &ncols, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream)); // sources are stack variables
+    const bool prof = ctx->profiling;
+    ctx->profiling = false;
+    rc = launch_block_prep(ctx, 1, ctx->d_one_lobin, ctx->d_one_numdata, ctx->d_one_blockfft);
+    if (!rc)
+        rc = launch_correlate(ctx, 1, ctx->d_one_blockfft, ctx->d_one_col, ctx->d_one_ncols,
+                              ctx->d_tmp, ACCELGPU_USELEN);
+    ctx->profiling = prof;
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(powers, ctx->d_tmp, elems * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (rlo_out)
+        *rlo_out = d.rlo;
+    return ACCELGPU_OK;
+}
+
+int accelgpu_summed_block(accelgpu_ctx *ctx, int block, int stage, float *powers)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if ((rc = check_ready(ctx, false))) return rc;
+    if (block < 0 || block >= ctx->nsearch || stage < 0 || stage >= ctx->setup.numharmstages ||
+        !powers) {
+        set_error("accelgpu_summed_block: block %d / stage %d out of range", block, stage);
+        return ACCELGPU_ERR_ARG;
+    }
+    const size_t elems = (size_t) ctx->numz * ACCELGPU_USELEN;
+    if ((rc = dev_reserve(&ctx->d_tmp, &ctx->tmp_cap, elems, false, ctx->stream))) return rc;
+    rc = launch_harmsum<true>(ctx, stage + 1, ctx->col0 + (int64_t) block * ACCELGPU_USELEN,
+                              ACCELGPU_USELEN, ctx->d_tmp, stage);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(powers, ctx->d_tmp, elems * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ACCELGPU_OK;
+}
+
+static int plane_span(accelgpu_ctx *ctx, int zind, int64_t col, int64_t count)
+{
+    if (!ctx->have_search || !ctx->d_plane) {
+        set_error("no plane allocated (accelgpu_set_search)");
+        return ACCELGPU_ERR_ARG;
+    }
+    if (zind < 0 || zind >= ctx->numz || col < 0 || count < 0 || col + count > ctx->setup.rlen) {
+        set_error("plane span z=%d col=%lld count=%lld out of range", zind, (long long) col,
+                  (long long) count);
+        return ACCELGPU_ERR_ARG;
+    }
+    return ACCELGPU_OK;
+}
+
+int accelgpu_get_plane(accelgpu_ctx *ctx, int zind, int64_t col, int64_t count, float *out)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if ((rc = plane_span(ctx, zind, col, count))) return rc;
+    HIPCHK(hipMemcpyAsync(out, ctx->d_plane + (size_t) zind * ctx->setup.rlen + col,
+                          (size_t) count * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ACCELGPU_OK;
+}
+
+int accelgpu_put_plane(accelgpu_ctx *ctx, int zind, int64_t col, int64_t count, const float *in)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if ((rc = plane_span(ctx, zind, col, count))) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->d_plane + (size_t) zind * ctx->setup.rlen + col, in,
+                          (size_t) count * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ACCELGPU_OK;
+}
+
+int accelgpu_set_profiling(accelgpu_ctx *ctx, int on)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    ctx->profiling = on != 0;
+    return ACCELGPU_OK;
+}
+
+int accelgpu_get_timings(accelgpu_ctx *ctx, int64_t launches[3], double total_ms[3], int reset)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 3; k++) {
+        for (auto &e : ctx->ev[k]) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
+            ctx->prof_ms[k] += ms;
+            ctx->prof_launches[k]++;
+            ctx->ev_pool.push_back(e);
+        }
+        ctx->ev[k].clear();
+        if (launches) launches[k] = ctx->prof_launches[k];
+        if (total_ms) total_ms[k] = ctx->prof_ms[k];
+        if (reset) {
+            ctx->prof_launches[k] = 0;
+            ctx->prof_ms[k] = 0;
+        }
+    }
+    return ACCELGPU_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,182 @@
+// fft_lds.hpp -- fixed-size complex float32 FFTs for gfx950, one transform per
+// workgroup, data in registers between three in-register radix passes and
+// exchanged twice through LDS.
+//
+//   N = R1 * R2 * R3,  NT threads,  E = N / NT values per thread.
+//
+//   pass 1: k = M1*a + b (M1 = R2*R3): radix-R1 over a for each b, then the
+//           large twiddle w_N^(b*n1) from a table laid out [n1][b] (coalesced).
+//   pass 2: b = R3*c + d: radix-R2 over c for each (n1, d), then w_M1^(e*d).
+//   pass 3: radix-R3 over d for each (n1, e); output index n1 + R1*(e + R2*f),
+//           so that consecutive threads hold consecutive outputs (coalesced
+//           global stores).
+//
+// LDS images are padded so that both the 8-byte writes and the 8-byte reads of
+// each exchange are bank-conflict free on CDNA4 (64 banks for ds_read_b64,
+// lane groups of 32; 32 banks and lane groups of 16 for ds_write_b64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace afft {
+
+typedef float c32 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ c32 cmul(c32 a, c32 b)
+{
+    return c32{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+// a * conj(b)
+__device__ __forceinline__ c32 cmul_conj(c32 a, c32 b)
+{
+    return c32{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y};
+}
+template <int DIR> __device__ __forceinline__ c32 mul_i(c32 a)
+{
+    return DIR > 0 ? c32{-a.y, a.x} : c32{a.y, -a.x};
+}
+
+// 32nd roots of unity, cos and sin of 2*pi*j/32.
+constexpr float kCos32[32] = {
+    1.f, 0.980785251f, 0.923879504f, 0.831469595f, 0.707106769f, 0.555570245f, 0.382683426f,
+    0.195090324f, 0.f, -0.195090324f, -0.382683426f, -0.555570245f, -0.707106769f,
+    -0.831469595f, -0.923879504f, -0.980785251f, -1.f, -0.980785251f, -0.923879504f,
+    -0.831469595f, -0.707106769f, -0.555570245f, -0.382683426f, -0.195090324f, 0.f,
+    0.195090324f, 0.382683426f, 0.555570245f, 0.707106769f, 0.831469595f, 0.923879504f,
+    0.980785251f};
+constexpr float kSin32[32] = {
+    0.f, 0.195090324f, 0.382683426f, 0.555570245f, 0.707106769f, 0.831469595f, 0.923879504f,
+    0.980785251f, 1.f, 0.980785251f, 0.923879504f, 0.831469595f, 0.707106769f, 0.555570245f,
+    0.382683426f, 0.195090324f, 0.f, -0.195090324f, -0.382683426f, -0.555570245f,
+    -0.707106769f, -0.831469595f, -0.923879504f, -0.980785251f, -1.f, -0.980785251f,
+    -0.923879504f, -0.831469595f, -0.707106769f, -0.555570245f, -0.382683426f, -0.195090324f};
+
+// In-register DFT of N = 2,4,...,32 points, natural order in and out:
+// v[k] <- sum_n v[n] * exp(DIR * 2*pi*i * n*k / N).  Everything is unrolled at
+// compile time so v[] lives in VGPRs.
+template <int N, int DIR> struct Dft {
+    template <int K> static __device__ __forceinline__ void combine(c32 *v, const c32 *e, const c32 *o)
+    {
+        c32 t;
+        if constexpr (K == 0) {
+            t = o[0];
+        } else if constexpr (4 * K == N) {
+            t = mul_i<DIR>(o[K]);
+        } else {
+            constexpr int J = K * (32 / N);
+            t = cmul(o[K], c32{kCos32[J], DIR * kSin32[J]});
+        }
+        v[K] = e[K] + t;
+        v[K + N / 2] = e[K] - t;
+        if constexpr (K + 1 < N / 2)
+            combine<K + 1>(v, e, o);
+    }
+    static __device__ __forceinline__ void run(c32 *v)
+    {
+        c32 e[N / 2], o[N / 2];
+#pragma unroll
+        for (int i = 0; i < N / 2; i++) {
+            e[i] = v[2 * i];
+            o[i] = v[2 * i + 1];
+        }
+        Dft<N / 2, DIR>::run(e);
+        Dft<N / 2, DIR>::run(o);
+        combine<0>(v, e, o);
+    }
+};
+template <int DIR> struct Dft<2, DIR> {
+    static __device__ __forceinline__ void run(c32 *v)
+    {
+        const c32 a = v[0], b = v[1];
+        v[0] = a + b;
+        v[1] = a - b;
+    }
+};
+template <int DIR> struct Dft<1, DIR> {
+    static __device__ __forceinline__ void run(c32 *) {}
+};
+
+template <int R1_, int R2_, int R3_, int NT_> struct Plan {
+    static constexpr int R1 = R1_, R2 = R2_, R3 = R3_, NT = NT_;
+    static constexpr int N = R1 * R2 * R3;
+    static constexpr int M1 = R2 * R3;
+    static constexpr int E = N / NT;           // values per thread
+    static constexpr int B1 = M1 / NT;         // radix-R1 butterflies per thread
+    static constexpr int B2 = R1 * R3 / NT;    // radix-R2 butterflies per thread
+    static constexpr int B3 = R1 * R2 / NT;    // radix-R3 butterflies per thread
+    static constexpr int S1 = M1 + 16;         // row stride of the first LDS image
+    static constexpr int S2 = R1 + 1;          // row stride of the second LDS image
+    static constexpr int LDS_ELEMS = (R1 * S1 > M1 * S2) ? R1 * S1 : M1 * S2;
+    static constexpr int LDS_BYTES = LDS_ELEMS * 8;
+    static_assert(B1 >= 1 && B2 >= 1 && B3 >= 1, "too many threads for this size");
+    static_assert(B1 * R1 == E && B2 * R2 == E && B3 * R3 == E, "uneven split");
+};
+
+// One transform.  load(u, a, b) returns input element M1*a + b for the thread's
+// u-th pass-1 butterfly (u, a are compile-time after unrolling); store(n, v)
+// receives output n.  tw1: [R1][M1] table of exp(DIR*2*pi*i*b*n1/N); tw2:
+// [R2][R3] table of exp(DIR*2*pi*i*e*d/M1).  Ends with all LDS reads done but
+// no trailing barrier: callers that loop must __syncthreads() before reuse.
+template <class P, int DIR, class Load, class Store>
+__device__ __forceinline__ void fft3(c32 *lds, const c32 *__restrict__ tw1,
+                                     const c32 *__restrict__ tw2, Load load, Store store)
+{
+    const int t = threadIdx.x;
+    c32 v[P::E];
+
+    // ---- pass 1 -------------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < P::B1; u++) {
+        const int b = t + P::NT * u;
+#pragma unroll
+        for (int a = 0; a < P::R1; a++)
+            v[u * P::R1 + a] = load(u, a, b);
+        Dft<P::R1, DIR>::run(&v[u * P::R1]);
+#pragma unroll
+        for (int n1 = 1; n1 < P::R1; n1++)
+            v[u * P::R1 + n1] = cmul(v[u * P::R1 + n1], tw1[n1 * P::M1 + b]);
+#pragma unroll
+        for (int n1 = 0; n1 < P::R1; n1++)
+            lds[n1 * P::S1 + b] = v[u * P::R1 + n1];
+    }
+    __syncthreads();
+
+    // ---- pass 2 -------------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < P::B2; u++) {
+        const int g = t + P::NT * u;
+        const int d = g % P::R3, n1 = g / P::R3;
+#pragma unroll
+        for (int c = 0; c < P::R2; c++)
+            v[u * P::R2 + c] = lds[n1 * P::S1 + P::R3 * c + d];
+    }
+    __syncthreads(); // every read of image 1 is done before image 2 overwrites it
+#pragma unroll
+    for (int u = 0; u < P::B2; u++) {
+        const int g = t + P::NT * u;
+        const int d = g % P::R3, n1 = g / P::R3;
+        Dft<P::R2, DIR>::run(&v[u * P::R2]);
+#pragma unroll
+        for (int e = 1; e < P::R2; e++)
+            v[u * P::R2 + e] = cmul(v[u * P::R2 + e], tw2[e * P::R3 + d]);
+#pragma unroll
+        for (int e = 0; e < P::R2; e++)
+            lds[(e * P::R3 + d) * P::S2 + n1] = v[u * P::R2 + e];
+    }
+    __syncthreads();
+
+    // ---- pass 3 -------------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < P::B3; u++) {
+        const int g = t + P::NT * u;
+        const int n1 = g % P::R1, e = g / P::R1;
+#pragma unroll
+        for (int d = 0; d < P::R3; d++)
+            v[u * P::R3 + d] = lds[(e * P::R3 + d) * P::S2 + n1];
+        Dft<P::R3, DIR>::run(&v[u * P::R3]);
+#pragma unroll
+        for (int f = 0; f < P::R3; f++)
+            store(g + P::R1 * P::R2 * f, v[u * P::R3 + f]);
+    }
+}
+
+} // namespace afft

@@ -1,0 +1,244 @@
+"""GPU parity tests: the HIP library (through its C ABI) against the CPU oracle.
+
+Bars:
+  * kernel bank, fundamental blocks, plane: float32 FFT pipelines with different
+    butterfly orders on the two sides -> compared relative to the largest value
+    in the compared array, tolerance 2e-5 (north-star bar for powers is 1e-3).
+  * harmonic sum + threshold on ONE shared plane: bit-exact (float adds in the
+    reference's order, integer index arithmetic).
+  * end-to-end candidate lists: identical (r, z, numharm) bins; power and sigma
+    within 1e-3 relative; cells within 2e-5 of a threshold are classified as
+    threshold-edge cases and may appear on one side only.
+"""
+import numpy as np
+import pytest
+
+from presto_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+USELEN = 7470
+PLANE_TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import presto_amd as pa
+    g = pa.AccelSearchGPU(0)
+    yield g
+    g.close()
+
+
+def _case(name, N, zmax=None, numharm=None, seed=None):
+    fft, c = synth.config_fft(name, N=N, seed=seed)
+    if zmax is not None:
+        c["zmax"] = zmax
+    if numharm is not None:
+        c["numharm"] = numharm
+    return fft, c
+
+
+def _both(gpu, oracle, fft, c, **kw):
+    args = dict(sigma=2.0, flo=1.0, fhi=1e9)
+    args.update(kw)
+    s = oracle.Search(fft, c["N"], c["dt"], c["zmax"], c["numharm"], nthreads=8, **args)
+    setup = gpu.configure(fft.size, c["N"], c["dt"], c["zmax"], c["numharm"], **args)
+    gpu.load_fft(fft)
+    return s, setup
+
+
+def test_setup_matches_oracle(gpu, oracle):
+    for zmax, numharm, N in ((0, 8, 1 << 20), (200, 16, 1 << 20), (300, 16, 1 << 21), (1200, 32, 1 << 20)):
+        fft = np.zeros(N // 2, dtype=np.complex64)
+        c = dict(N=N, dt=64e-6, zmax=zmax, numharm=numharm)
+        s = oracle.Search(fft, N, c["dt"], zmax, numharm, fhi=1e9, alloc_plane=False)
+        import presto_amd as pa
+        p = pa.plan(fft.size, N, c["dt"], zmax, numharm, fhi=1e9)
+        assert (p.rlo, p.highestbin, p.numz, p.fftlen, p.numharmstages) == \
+            (s.rlo, s.highestbin, s.numz, s.fftlen, s.numstages)
+        assert p.num_search_blocks == s.num_blocks and p.num_prepop_blocks == s.num_prepop
+        assert list(p.numindep)[:p.numharmstages] == list(s.numindep)
+        assert np.array_equal(np.array(list(p.powcut)[:p.numharmstages], dtype=np.float32), s.powcut)
+        assert p.rlen == s.rlen
+
+
+@pytest.mark.parametrize("zmax", [0, 50, 200, 300, 1200])
+def test_kernel_bank(gpu, oracle, zmax):
+    gpu.create_subharminfos(zmax)
+    L = oracle.lib()
+    fftlen = L.orc_calc_fftlen(1, 1, zmax)
+    numz = (zmax // 2) * 2 + 1
+    picks = sorted(set([0, 1, numz // 4, numz // 2, numz - 2, numz - 1]) & set(range(numz)))
+    for zi in picks:
+        want, _ = oracle.init_kernel(-zmax + 2 * zi, fftlen)
+        got = gpu.kernel(zi, fftlen)
+        scale = np.abs(want).max()
+        assert np.abs(got - want).max() <= 4e-6 * scale, (zmax, zi)
+
+
+@pytest.mark.parametrize("name,N,zmax,numharm", [("cfg1", 1 << 20, 0, 8), ("cfg2", 1 << 19, 200, 16),
+                                                 ("cfg2", 1 << 18, 300, 16), ("cfg5", 1 << 19, 1200, 32)])
+def test_fundamental_blocks(gpu, oracle, name, N, zmax, numharm):
+    fft, c = _case(name, N, zmax, numharm)
+    s, setup = _both(gpu, oracle, fft, c)
+    starts = [8.0, s.rlo, s.rlo + 3735.0 * (s.num_blocks - 1)]
+    for startr in starts:
+        want, rlo_w = s.fund_block(startr)
+        got, rlo_g = gpu.subharm_ffdot_plane(startr)
+        assert rlo_w == rlo_g
+        scale = want.max()
+        err = np.abs(got - want).max() / scale
+        assert err <= PLANE_TOL, (startr, err)
+    s.close()
+
+
+def test_ragged_ends_and_lobin(gpu, oracle):
+    """Windows that run off both ends of the file (zero padding) and a file that
+    starts at a non-zero bin (-lobin)."""
+    fft, c = _case("cfg2", 1 << 17, 200, 4)
+    s, setup = _both(gpu, oracle, fft, c)
+    for startr in (8.0, float(fft.size - 3000), float(fft.size - 500)):
+        want, _ = s.fund_block(startr)
+        got, _ = gpu.subharm_ffdot_plane(startr)
+        assert np.abs(got - want).max() <= PLANE_TOL * want.max()
+    s.close()
+    s, setup = _both(gpu, oracle, fft, c, lobin=1000, flo=0.0)
+    assert setup.rlo == 1000
+    for startr in (1000.0, 1000.0 + 3735.0):
+        want, _ = s.fund_block(startr)
+        got, _ = gpu.subharm_ffdot_plane(startr)
+        assert np.abs(got - want).max() <= PLANE_TOL * want.max()
+    s.close()
+
+
+def test_photon_normalisation(gpu, oracle):
+    fft, c = _case("cfg1", 1 << 18, 20, 2)
+    fft = fft.copy()
+    fft[0] = np.complex64(complex(7.5, 0.3))       # "number of photons" lives in bin 0
+    s = oracle.Search(fft, c["N"], c["dt"], 20, 2, fhi=1e9, photon=True)
+    setup = gpu.configure(fft.size, c["N"], c["dt"], 20, 2, fhi=1e9, photon_nph=float(fft[0].real))
+    gpu.load_fft(fft)
+    want, _ = s.fund_block(s.rlo)
+    got, _ = gpu.subharm_ffdot_plane(s.rlo)
+    assert np.abs(got - want).max() <= PLANE_TOL * want.max()
+    s.close()
+
+
+@pytest.mark.parametrize("name,N,zmax,numharm", [("cfg1", 1 << 19, 0, 8), ("cfg2", 1 << 18, 200, 16),
+                                                 ("cfg2", 1 << 18, 40, 32)])
+def test_harmonic_sum_and_threshold_bit_exact(gpu, oracle, name, N, zmax, numharm):
+    """Both sides sum and threshold the SAME plane (the GPU's): every hit must
+    match bit for bit, in the same order, and so must the candidate lists."""
+    import presto_amd as pa
+    fft, c = _case(name, N, zmax, numharm)
+    s, setup = _both(gpu, oracle, fft, c)
+    gpu.fill_plane()
+    s.set_plane(gpu.plane())
+    want_hits, want_cands = s.search_plane()
+    got = gpu.search_plane()
+    assert len(got) == len(want_hits) and len(got) > 0
+    assert np.array_equal(got["power"].view(np.uint32), want_hits["power"].view(np.uint32))
+    assert np.array_equal(1 << got["stage"], want_hits["numharm"])
+    assert np.array_equal(got["zind"], want_hits["zind"])
+    assert np.array_equal(got["rind"], want_hits["rind"])
+    assert np.array_equal(got["block"], want_hits["block"])
+    cands, sig, added = pa.api.replay_candidates(setup, got)
+    assert np.array_equal(added, want_hits["added"])
+    np.testing.assert_allclose(sig, want_hits["sigma"], rtol=1e-6)
+    assert len(cands) == len(want_cands)
+    assert np.array_equal(cands["r"], want_cands["r"]) and np.array_equal(cands["z"], want_cands["z"])
+    assert np.array_equal(cands["numharm"], want_cands["numharm"])
+    assert np.array_equal(cands["power"].view(np.uint32), want_cands["power"].view(np.uint32))
+    # summed blocks after every stage, straight from the getter
+    blk = min(1, setup.num_search_blocks - 1)
+    rlo_b = int(s.rlo) + blk * 3735
+    pw = np.ascontiguousarray(s.plane()[:, 2 * rlo_b: 2 * rlo_b + USELEN])
+    assert np.array_equal(gpu.summed_block(blk, 0), pw)
+    for stage in range(1, setup.numharmstages):
+        for h in range(1, 1 << stage, 2):
+            s.inmem_add(pw, rlo_b, 1 << stage, h)
+        assert np.array_equal(gpu.summed_block(blk, stage).view(np.uint32), pw.view(np.uint32)), stage
+    s.close()
+
+
+def _compare_lists(setup, got_hits, want_hits, tol_edge=PLANE_TOL * 4):
+    """Match hits by (stage, zind, rind); unmatched ones must sit at a threshold."""
+    powcut = np.array(list(setup.powcut), dtype=np.float64)
+    key = lambda st, z, r: (st.astype(np.int64) << 56) | (z.astype(np.int64) << 40) | r
+    kg = key(got_hits["stage"], got_hits["zind"], got_hits["rind"])
+    kw = key(np.log2(want_hits["numharm"]).astype(np.int64), want_hits["zind"], want_hits["rind"])
+    common, ig, iw = np.intersect1d(kg, kw, return_indices=True)
+    rel = np.abs(got_hits["power"][ig] - want_hits["power"][iw]) / want_hits["power"][iw]
+    only_g = np.setdiff1d(np.arange(len(kg)), ig)
+    only_w = np.setdiff1d(np.arange(len(kw)), iw)
+    edge_g = np.abs(got_hits["power"][only_g] / powcut[got_hits["stage"][only_g]] - 1.0)
+    st_w = np.log2(want_hits["numharm"][only_w]).astype(int)
+    edge_w = np.abs(want_hits["power"][only_w] / powcut[st_w] - 1.0)
+    return rel, edge_g, edge_w
+
+
+@pytest.mark.parametrize("name,N,zmax,numharm", [("cfg1", 1 << 20, 0, 8), ("cfg2", 1 << 19, 200, 16),
+                                                 ("cfg5", 1 << 18, 1200, 32)])
+def test_end_to_end_candidates(gpu, oracle, name, N, zmax, numharm):
+    fft, c = _case(name, N, zmax, numharm)
+    s, setup = _both(gpu, oracle, fft, c)
+    want_hits, want_cands = s.run()
+    got_hits, got_cands, sig, added = gpu.search()
+    rel, edge_g, edge_w = _compare_lists(setup, got_hits, want_hits)
+    assert len(rel) >= 0.98 * max(len(want_hits), 1)
+    assert rel.max() <= 1e-3                      # north-star bar
+    assert rel.max() <= 10 * PLANE_TOL            # what we actually reach
+    assert (edge_g <= 4 * PLANE_TOL).all() and (edge_w <= 4 * PLANE_TOL).all()
+    if len(edge_g) == 0 and len(edge_w) == 0:
+        # no threshold-edge flips: the final lists must name the same bins
+        assert len(got_cands) == len(want_cands)
+        assert np.array_equal(got_cands["r"], want_cands["r"])
+        assert np.array_equal(got_cands["z"], want_cands["z"])
+        assert np.array_equal(got_cands["numharm"], want_cands["numharm"])
+        np.testing.assert_allclose(got_cands["power"], want_cands["power"], rtol=1e-3)
+        np.testing.assert_allclose(got_cands["sigma"], want_cands["sigma"], rtol=1e-3, atol=1e-3)
+    # the injected pulsar is recovered
+    best = got_cands[np.argmax(got_cands["sigma"])]
+    assert best["sigma"] > 6
+    s.close()
+
+
+def test_injected_pulsar_recovered_at_known_rz(gpu):
+    """Oracle-free property: a drifting tone injected at (r0, z0) is found in the
+    matching z row at r0, with close to the injected power."""
+    numbins = 1 << 18
+    N = 2 * numbins
+    r0, z0, amp = 50000.25, 80.0, 12.0
+    fft = synth.noise_fft(numbins, 7, lines=[(r0, z0, amp)])
+    setup = gpu.configure(numbins, N, 1e-3, 200, 1, flo=0.01, fhi=1e9)
+    gpu.load_fft(fft)
+    hits, cands, sig, added = gpu.search()
+    best = cands[np.argmax(cands["power"])]
+    assert abs(best["r"] - r0) <= 0.5 and abs(best["z"] - z0) <= 2.0
+    assert 0.7 * amp * amp <= best["power"] <= 1.4 * amp * amp
+
+
+def test_async_launch_collect_equals_run(gpu):
+    numbins = 1 << 17
+    fft = synth.noise_fft(numbins, 11, lines=[(30000.0, -20.0, 9.0)])
+    gpu.configure(numbins, 2 * numbins, 1e-3, 100, 8, flo=0.02, fhi=1e9)
+    gpu.load_fft(fft)
+    a = gpu.run()
+    gpu.run_launch()
+    b = gpu.run_collect()
+    assert np.array_equal(a, b)
+    # a tiny caller buffer forces the overflow path and still returns every hit
+    c = gpu.run(max_hits=1)
+    assert np.array_equal(a, c)
+
+
+def test_errors_are_reported(gpu):
+    import presto_amd as pa
+    with pytest.raises(pa.AccelGPUError):
+        pa.plan(1 << 16, 1 << 17, 1e-3, 200, 3)            # numharm not a power of two
+    with pytest.raises(pa.AccelGPUError):
+        pa.plan(1 << 16, 1 << 17, 1e-3, 200, 8, flo=1e6)   # flo above the spectrum
+    g = pa.AccelSearchGPU(0)
+    with pytest.raises(pa.AccelGPUError):
+        g.fill_plane()                                      # nothing configured
+    g.close()
