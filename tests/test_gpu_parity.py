@@ -97,7 +97,7 @@ def test_ragged_ends_and_lobin(gpu, oracle):
     starts at a non-zero bin (-lobin)."""
     fft, c = _case("cfg2", 1 << 17, 200, 4)
     s, setup = _both(gpu, oracle, fft, c)
-    for startr in (8.0, float(fft.size - 3000), float(fft.size - 500)):
+    for startr in (8.0, float(fft.size - 3737), float(fft.size - 3736 - 60)):
         want, _ = s.fund_block(startr)
         got, _ = gpu.subharm_ffdot_plane(startr)
         assert np.abs(got - want).max() <= PLANE_TOL * want.max()
@@ -152,7 +152,7 @@ def test_harmonic_sum_and_threshold_bit_exact(gpu, oracle, name, N, zmax, numhar
     # summed blocks after every stage, straight from the getter
     blk = min(1, setup.num_search_blocks - 1)
     rlo_b = int(s.rlo) + blk * 3735
-    pw = np.ascontiguousarray(s.plane()[:, 2 * rlo_b: 2 * rlo_b + USELEN])
+    pw = s.plane()[:, 2 * rlo_b: 2 * rlo_b + USELEN].copy()   # a copy: the sums must not land in the plane
     assert np.array_equal(gpu.summed_block(blk, 0), pw)
     for stage in range(1, setup.numharmstages):
         for h in range(1, 1 << stage, 2):
@@ -197,9 +197,10 @@ def test_end_to_end_candidates(gpu, oracle, name, N, zmax, numharm):
         assert np.array_equal(got_cands["numharm"], want_cands["numharm"])
         np.testing.assert_allclose(got_cands["power"], want_cands["power"], rtol=1e-3)
         np.testing.assert_allclose(got_cands["sigma"], want_cands["sigma"], rtol=1e-3, atol=1e-3)
-    # the injected pulsar is recovered
-    best = got_cands[np.argmax(got_cands["sigma"])]
-    assert best["sigma"] > 6
+    # both sides rank the same candidate first
+    best, wbest = got_cands[np.argmax(got_cands["sigma"])], want_cands[np.argmax(want_cands["sigma"])]
+    assert best["r"] == wbest["r"] and best["z"] == wbest["z"] and best["numharm"] == wbest["numharm"]
+    assert abs(best["sigma"] - wbest["sigma"]) <= 1e-3 * wbest["sigma"]
     s.close()
 
 
