@@ -337,86 +337,160 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate(
 }
 
 // ---------------------------------------------------------------------------
-// Harmonic sum + threshold.  One thread per fundamental column (absolute
-// half-bin index rind = col0 + c), looping over z rows.  For stage s >= 1 and
-// odd h < 2^s the sub-harmonic cell is
-//   row  ztab[harm][zi]                       (calc_required_z / index_from_z)
+// Harmonic sum + threshold.  A workgroup owns 512*J consecutive fundamental
+// columns (absolute half-bin index rind = col0 + c) and walks every z row; a
+// thread owns J column pairs (2t, 2t+1) + 512*j, so the fundamental comes in
+// as 8-byte loads.  For stage s >= 1 and odd h < 2^s the sub-harmonic cell is
+//   row  rowoff[zi][harm]  = 4 * rlen * index_from_z(calc_required_z(h/2^s, z))
 //   col  (int)(rind * h / 2^s + 0.5) = (rind*h + 2^(s-1)) >> s   (exact: dyadic)
 // and the running float sum is accumulated in the reference's order
 // (fundamental, 1/2, 1/4, 3/4, 1/8, ...).  After each stage the sum is compared
-// with powcut[stage]; hits are compacted per wavefront with a ballot and one
-// atomic per wave.
+// with powcut[stage]; crossings are compacted per wavefront with a ballot and
+// one atomic per wave.  Row offsets are wave-uniform (scalar loads, scalar base
+// + 32-bit lane offset addressing), so the loop is loads and adds only.
 // DUMP: instead of thresholding, write the sums after stage `dump_stage`.
 // ---------------------------------------------------------------------------
 struct HarmParams {
     float powcut[6];
 };
 
-template <int NSTAGES, bool DUMP>
+template <int NSTAGES> struct HarmShape {
+    static constexpr int NH = (1 << (NSTAGES - 1)) - 1; // sub-harmonics summed in total
+    static constexpr int NHS = NH > 0 ? NH : 1;         // row stride of the offset table
+};
+
+// C = columns per thread: 1 (dword loads, least registers, most waves in
+// flight) or an even number 2*J (8-byte fundamental loads, J pairs 512 apart).
+// Workgroup -> tile mapping: blockIdx.x is dealt round-robin over the 8 XCDs, so
+// tile = (b % 8) * ceil(T/8) + b / 8 hands each XCD one contiguous run of tiles:
+// neighbouring tiles then share source lines in that XCD's L2 and each XCD
+// streams long contiguous pieces of every plane row.
+template <int NSTAGES, int C, bool DUMP>
 __global__ __launch_bounds__(256) void k_harmsum(
     const float *__restrict__ plane, int64_t rlen, int numz, int64_t col0, int64_t ncols,
-    const int *__restrict__ ztab, HarmParams prm, DevHit *__restrict__ hits,
-    unsigned int *__restrict__ count, unsigned int max_hits, int zchunk, float *__restrict__ dump,
-    int dump_stage)
+    const int64_t *__restrict__ rowoff, const uint32_t *__restrict__ rowchg, HarmParams prm,
+    DevHit *__restrict__ hits, unsigned int *__restrict__ count, unsigned int max_hits,
+    float *__restrict__ dump, int dump_stage, int xcd_remap)
 {
-    constexpr int NH = (1 << (NSTAGES - 1)) - 1; // sub-harmonics summed in total
-    const int64_t c = (int64_t) blockIdx.x * 256 + threadIdx.x;
-    const bool live = c < ncols;
-    const int64_t rind = col0 + (live ? c : 0);
-    const int z0 = blockIdx.y * zchunk;
-    const int z1 = min(z0 + zchunk, numz);
+    constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
+    constexpr int J = C > 1 ? C / 2 : 1;
+    constexpr int TILE = 256 * C;
+    static_assert(C == 1 || C % 2 == 0, "C is 1 or even");
+    const int lane = threadIdx.x & 63;
+    unsigned int tile = blockIdx.x;
+    if (xcd_remap) {
+        const unsigned int per = (gridDim.x + 7) / 8;
+        tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+        if ((int64_t) tile * TILE >= ncols)
+            return; // padding slot of the remapped grid (whole workgroup)
+    }
+    const int64_t cbase = (int64_t) tile * TILE + (C > 1 ? 2 : 1) * threadIdx.x;
 
-    int64_t src[NH > 0 ? NH : 1];
+    int64_t rind[C];
+    bool live[C];
+    uint32_t off[NHS][C]; // byte offset of each source column inside its row
+#pragma unroll
+    for (int j = 0; j < J; j++)
+#pragma unroll
+        for (int k = 0; k < (C > 1 ? 2 : 1); k++) {
+            const int64_t c = cbase + 512 * j + k;
+            live[2 * j + k] = c < ncols;
+            rind[2 * j + k] = col0 + (c < ncols ? c : (int64_t) k); // dead lanes read a valid cell
+        }
     {
         int i = 0;
 #pragma unroll
-        for (int s = 1; s < NSTAGES; s++) {
+        for (int s = 1; s < NSTAGES; s++)
 #pragma unroll
             for (int h = 1; h < (1 << s); h += 2) {
-                src[i] = (rind * h + (1 << (s - 1))) >> s;
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    off[i][c] = (uint32_t) (((rind[c] * h + (1 << (s - 1))) >> s) << 2);
                 i++;
             }
-        }
     }
-    const int lane = threadIdx.x & 63;
 
-    for (int zi = z0; zi < z1; zi++) {
-        float p = plane[(size_t) zi * rlen + rind];
-        float v[NH > 0 ? NH : 1];
+    const char *pbytes = reinterpret_cast<const char *>(plane);
+    // Sub-harmonic values live in registers across z rows: harmonic h/2^s maps
+    // about 2^s/h consecutive rows to one source row, so a value is re-read only
+    // when rowchg[zi] says its source row moved (wave-uniform branch).  Every
+    // plane cell is then fetched once per use instead of relying on L2 retention.
+    float v[NHS][C];
+    for (int zi = 0; zi < numz; zi++) {
+        const float *frow = plane + (size_t) zi * (size_t) rlen;
+        float p[C];
+        if constexpr (C == 1) {
+            p[0] = frow[rind[0]];
+        } else {
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const float2 f = *reinterpret_cast<const float2 *>(frow + rind[2 * j]);
+                p[2 * j] = f.x;
+                p[2 * j + 1] = f.y;
+            }
+        }
+        const uint32_t chg = NH > 0 ? rowchg[zi] : 0u;
 #pragma unroll
         for (int i = 0; i < NH; i++) {
-            const int zz = ztab[i * numz + zi];
-            v[i] = plane[(size_t) zz * rlen + src[i]];
-        }
-        int i = 0;
+            if (chg & (1u << i)) {
+                const char *row = pbytes + rowoff[(size_t) zi * NHS + i];
 #pragma unroll
-        for (int s = 0; s < NSTAGES; s++) {
-            if (s > 0) {
-#pragma unroll
-                for (int h = 1; h < (1 << s); h += 2) {
-                    p += v[i];
-                    i++;
-                }
+                for (int c = 0; c < C; c++)
+                    v[i][c] = *reinterpret_cast<const float *>(row + off[i][c]);
             }
-            if constexpr (DUMP) {
-                if (s == dump_stage && live)
-                    dump[(size_t) zi * ncols + c] = p;
-            } else {
-                const bool hit = live && (p > prm.powcut[s]);
-                const unsigned long long mask = __ballot(hit);
-                if (mask) {
-                    unsigned int base = 0;
-                    const int leader = __ffsll((long long) mask) - 1;
-                    if (lane == leader)
-                        base = atomicAdd(count, (unsigned int) __popcll(mask));
-                    base = __shfl(base, leader);
-                    if (hit) {
-                        const unsigned int pos =
-                            base + (unsigned int) __popcll(mask & ((1ull << lane) - 1ull));
-                        if (pos < max_hits)
-                            hits[pos] = DevHit{p, ((uint32_t) s << 16) | (uint32_t) zi, rind};
+        }
+        float ps[NSTAGES][C];
+        bool any = false;
+        {
+            int i = 0;
+#pragma unroll
+            for (int s = 0; s < NSTAGES; s++) {
+                if (s > 0) {
+#pragma unroll
+                    for (int h = 1; h < (1 << s); h += 2) {
+#pragma unroll
+                        for (int c = 0; c < C; c++)
+                            p[c] += v[i][c];
+                        i++;
                     }
                 }
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    ps[s][c] = p[c];
+                    any |= live[c] && (p[c] > prm.powcut[s]);
+                }
+            }
+        }
+        if constexpr (DUMP) {
+#pragma unroll
+            for (int s = 0; s < NSTAGES; s++)
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    if (s == dump_stage && live[c])
+                        dump[(size_t) zi * ncols + (rind[c] - col0)] = ps[s][c];
+        } else {
+            if (__ballot(any)) { // rare: some lane of this wave crossed a threshold
+#pragma unroll
+                for (int s = 0; s < NSTAGES; s++)
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        const bool hit = live[c] && (ps[s][c] > prm.powcut[s]);
+                        const unsigned long long mask = __ballot(hit);
+                        if (mask) {
+                            unsigned int base = 0;
+                            const int leader = __ffsll((long long) mask) - 1;
+                            if (lane == leader)
+                                base = atomicAdd(count, (unsigned int) __popcll(mask));
+                            base = __shfl(base, leader);
+                            if (hit) {
+                                const unsigned int pos =
+                                    base + (unsigned int) __popcll(mask & ((1ull << lane) - 1ull));
+                                if (pos < max_hits)
+                                    hits[pos] = DevHit{ps[s][c], ((uint32_t) s << 16) | (uint32_t) zi,
+                                                       rind[c]};
+                            }
+                        }
+                    }
             }
         }
     }

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -29,6 +30,7 @@ namespace {
 typedef afft::Plan<16, 16, 16, 256> P4K;
 typedef afft::Plan<32, 16, 16, 256> P8K;
 typedef afft::Plan<32, 16, 32, 512> P16K;
+
 
 #define HIPCHK(expr)                                                                     \
     do {                                                                                 \
@@ -79,8 +81,10 @@ struct accelgpu_ctx {
     size_t blockfft_cap = 0;
     float *d_plane = nullptr;
     size_t plane_cap = 0;
-    int *d_ztab = nullptr;
-    size_t ztab_cap = 0;
+    int64_t *d_rowoff = nullptr; // [numz][NH] byte offsets of the sub-harmonic source rows
+    size_t rowoff_cap = 0;
+    uint32_t *d_rowchg = nullptr; // [numz] bit i: source row of harmonic i differs from row zi-1
+    size_t rowchg_cap = 0;
 
     // hits
     DevHit *d_hits = nullptr;
@@ -255,26 +259,39 @@ int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const i
     return prof_end(ctx, 1, &ep);
 }
 
-template <bool DUMP>
-int launch_harmsum(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, float *dump,
-                   int dump_stage)
+// J = column pairs per thread of the harmonic-sum kernel.
+template <bool DUMP, int J>
+int launch_harmsum_j(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, float *dump,
+                     int dump_stage)
 {
     accelk::HarmParams prm;
     for (int i = 0; i < 6; i++)
         prm.powcut[i] = i < ctx->setup.numharmstages ? ctx->setup.powcut[i] : INFINITY;
-    const int numz = ctx->numz;
-    const int zchunk = numz; // one workgroup walks every z row of its 256 columns
-    const dim3 grid((unsigned) ((ncols + 255) / 256), (numz + zchunk - 1) / zchunk);
+    constexpr int C = J > 0 ? 2 * J : 1;
+    const int remap = getenv("ACCELGPU_NO_XCD_REMAP") ? 0 : 1;
+    const int lds_pad = getenv("ACCELGPU_HS_LDS") ? atoi(getenv("ACCELGPU_HS_LDS")) : 0; // occupancy experiments
+    unsigned ntiles = (unsigned) ((ncols + 256 * C - 1) / (256 * C));
+    if (remap)
+        ntiles = ((ntiles + 7) / 8) * 8;
+    const dim3 grid(ntiles);
     const unsigned int cap = (unsigned int) std::min<size_t>(ctx->hits_cap, 0xFFFFFFFFu);
     EventPair ep;
     if (!DUMP) {
         int rc = prof_begin(ctx, 2, &ep);
         if (rc) return rc;
     }
+    // the offset table is laid out for the configured number of stages; a dump
+    // of an earlier stage still runs the full-depth kernel and picks its stage
+    if (nstages != ctx->setup.numharmstages) {
+        set_error("harmonic-sum launch for %d stages but the table holds %d", nstages,
+                  ctx->setup.numharmstages);
+        return ACCELGPU_ERR_ARG;
+    }
 #define LAUNCH_HS(NS)                                                                        \
-    hipLaunchKernelGGL((accelk::k_harmsum<NS, DUMP>), grid, dim3(256), 0, ctx->stream,       \
-                       ctx->d_plane, ctx->setup.rlen, numz, col0, ncols, ctx->d_ztab, prm,    \
-                       ctx->d_hits, ctx->d_count, cap, zchunk, dump, dump_stage)
+    hipLaunchKernelGGL((accelk::k_harmsum<NS, C, DUMP>), grid, dim3(256), lds_pad, ctx->stream,     \
+                       ctx->d_plane, ctx->setup.rlen, ctx->numz, col0, ncols, ctx->d_rowoff,   \
+                       ctx->d_rowchg,                                                         \
+                       prm, ctx->d_hits, ctx->d_count, cap, dump, dump_stage, remap)
     switch (nstages) {
     case 1: LAUNCH_HS(1); break;
     case 2: LAUNCH_HS(2); break;
@@ -291,6 +308,23 @@ int launch_harmsum(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, 
     if (!DUMP)
         return prof_end(ctx, 2, &ep);
     return ACCELGPU_OK;
+}
+
+template <bool DUMP>
+int launch_harmsum(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, float *dump,
+                   int dump_stage)
+{
+    // Few harmonics: little data per thread, so take it in 8-byte pieces, two
+    // pairs per thread, to keep enough bytes in flight; many harmonics: one
+    // column per thread keeps registers low and waves plentiful.
+    int j = nstages <= 2 ? 2 : 0;
+    if (const char *e = getenv("ACCELGPU_HARM_J"))
+        j = atoi(e);
+    if (j == 2)
+        return launch_harmsum_j<DUMP, 2>(ctx, nstages, col0, ncols, dump, dump_stage);
+    if (j == 1)
+        return launch_harmsum_j<DUMP, 1>(ctx, nstages, col0, ncols, dump, dump_stage);
+    return launch_harmsum_j<DUMP, 0>(ctx, nstages, col0, ncols, dump, dump_stage);
 }
 
 int reserve_hits(accelgpu_ctx *ctx, size_t want)
@@ -490,7 +524,7 @@ void accelgpu_destroy(accelgpu_ctx *ctx)
     void *dev[] = {ctx->d_bank, ctx->tw_inv.tw1, ctx->tw_inv.tw2, ctx->tw_fwd_full.tw1,
                    ctx->tw_fwd_full.tw2, ctx->tw_fwd_half.tw1, ctx->tw_fwd_half.tw2,
                    ctx->d_fft_owned, ctx->d_blk_lobin, ctx->d_blk_col, ctx->d_blk_numdata,
-                   ctx->d_blk_ncols, ctx->d_blockfft, ctx->d_plane, ctx->d_ztab, ctx->d_hits,
+                   ctx->d_blk_ncols, ctx->d_blockfft, ctx->d_plane, ctx->d_rowoff, ctx->d_rowchg, ctx->d_hits,
                    ctx->d_count, ctx->d_tmp, ctx->d_one_lobin, ctx->d_one_col,
                    ctx->d_one_numdata, ctx->d_one_ncols, ctx->d_one_blockfft};
     for (void *p : dev)
@@ -735,10 +769,11 @@ int accelgpu_set_search(accelgpu_ctx *ctx, const accelgpu_setup *s, int norm_typ
     if (fresh || !same_geometry)
         HIPCHK(hipMemsetAsync(ctx->d_plane, 0, plane_elems * sizeof(float), ctx->stream));
 
-    // sub-harmonic row table, in summing order (stage ascending, odd harmonic ascending)
+    // sub-harmonic source rows, in summing order (stage ascending, odd harmonic
+    // ascending), as byte offsets into the plane: [numz][nh]
     const int nh = (1 << (s->numharmstages - 1)) - 1;
     if (nh > 0) {
-        std::vector<int> ztab((size_t) nh * ctx->numz);
+        std::vector<int64_t> tab((size_t) nh * ctx->numz);
         int i = 0;
         for (int st = 1; st < s->numharmstages; st++)
             for (int h = 1; h < (1 << st); h += 2, i++) {
@@ -746,12 +781,26 @@ int accelgpu_set_search(accelgpu_ctx *ctx, const accelgpu_setup *s, int norm_typ
                 for (int zi = 0; zi < ctx->numz; zi++) {
                     const int zz = (int) s->zlo + zi * 2;
                     const int subz = accelhost::calc_required_z(f, zz);
-                    ztab[(size_t) i * ctx->numz + zi] = accelhost::index_from_z(subz, s->zlo);
+                    const int zind = accelhost::index_from_z(subz, s->zlo);
+                    tab[(size_t) zi * nh + i] = (int64_t) zind * ctx->setup.rlen * 4;
                 }
             }
-        if ((rc = dev_reserve(&ctx->d_ztab, &ctx->ztab_cap, ztab.size(), false, ctx->stream)))
+        if ((rc = dev_reserve(&ctx->d_rowoff, &ctx->rowoff_cap, tab.size(), false, ctx->stream)))
             return rc;
-        HIPCHK(hipMemcpy(ctx->d_ztab, ztab.data(), ztab.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ctx->d_rowoff, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        std::vector<uint32_t> chg((size_t) ctx->numz);
+        for (int zi = 0; zi < ctx->numz; zi++) {
+            uint32_t m = 0;
+            for (int k = 0; k < nh; k++)
+                if (zi == 0 || tab[(size_t) zi * nh + k] != tab[(size_t) (zi - 1) * nh + k])
+                    m |= 1u << k;
+            chg[zi] = m;
+        }
+        if ((rc = dev_reserve(&ctx->d_rowchg, &ctx->rowchg_cap, chg.size(), false, ctx->stream)))
+            return rc;
+        HIPCHK(hipMemcpy(ctx->d_rowchg, chg.data(), chg.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    } else if ((rc = dev_reserve(&ctx->d_rowoff, &ctx->rowoff_cap, 1, false, ctx->stream))) {
+        return rc;
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->have_search = true;
@@ -887,7 +936,7 @@ int accelgpu_summed_block(accelgpu_ctx *ctx, int block, int stage, float *powers
     }
     const size_t elems = (size_t) ctx->numz * ACCELGPU_USELEN;
     if ((rc = dev_reserve(&ctx->d_tmp, &ctx->tmp_cap, elems, false, ctx->stream))) return rc;
-    rc = launch_harmsum<true>(ctx, stage + 1, ctx->col0 + (int64_t) block * ACCELGPU_USELEN,
+    rc = launch_harmsum<true>(ctx, ctx->setup.numharmstages, ctx->col0 + (int64_t) block * ACCELGPU_USELEN,
                               ACCELGPU_USELEN, ctx->d_tmp, stage);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(powers, ctx->d_tmp, elems * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
