@@ -160,6 +160,21 @@ int accelgpu_replay_candidates(const accelgpu_setup *setup, const accelgpu_hit *
                                int64_t n_hits, accelgpu_cand *cands, int64_t max_cands,
                                int64_t *n_cands, float *sigma_out, int32_t *added);
 
+/* ---- per-block forms (hosts that keep the reference's call sequence) ------ */
+/* Copies a host block (numz*USELEN floats, [z][r]) into the in-HBM plane at
+ * column 2*rlo.  ref: fund_to_ffdotplane(), src/accel_utils.c:1076-1090. */
+int accelgpu_fund_to_ffdotplane(accelgpu_ctx *ctx, const float *powers, int32_t rlo);
+/* powers[z][j] += plane[zind(z)][(int)((2*rlo+j)*harmnum/numharm + 0.5)] for one
+ * sub-harmonic, on the GPU; `powers` is the host block, updated in place.
+ * ref: inmem_add_ffdotpows(), src/accel_utils.c:1160-1208. */
+int accelgpu_inmem_add_ffdotpows(accelgpu_ctx *ctx, float *powers, int32_t rlo, int numharm,
+                                 int harmnum);
+/* Threshold scan of a host block against powcut[log2 numharm] on the GPU; hits
+ * come back in the reference's scan order (z row, then r).
+ * ref: the scan of search_ffdotpows(), src/accel_utils.c:1272-1283. */
+int accelgpu_search_ffdotpows(accelgpu_ctx *ctx, const float *powers, int32_t rlo, int numharm,
+                              accelgpu_hit *hits, int64_t max_hits, int64_t *n_hits);
+
 /* ---- parity getters ------------------------------------------------------ */
 /* One fundamental block computed on its own: numz*USELEN floats, row-major
  * [z][r], exactly the ffdotpows.powers matrix.  ref: subharm_ffdot_plane(1,1,

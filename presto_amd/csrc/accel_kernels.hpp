@@ -496,4 +496,51 @@ __global__ __launch_bounds__(256) void k_harmsum(
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Block-granular forms of the same steps, for hosts that keep the reference's
+// per-block call sequence (one block of numz x USELEN powers at a time).
+// ---------------------------------------------------------------------------
+// blockpow[zi][j] += plane[zind[zi]][(int)((2*rlo + j) * h / 2^s + 0.5)]
+__global__ __launch_bounds__(256) void k_block_add_harm(float *__restrict__ blockpow,
+                                                       const float *__restrict__ plane,
+                                                       int64_t rlen, int rlo, int s, int h,
+                                                       const int *__restrict__ zind)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int zi = blockIdx.y;
+    if (j >= USELEN)
+        return;
+    const int64_t rr = (int64_t) 2 * rlo + j;
+    const int64_t src = (rr * h + (1 << (s - 1))) >> s;
+    blockpow[(size_t) zi * USELEN + j] += plane[(size_t) zind[zi] * rlen + src];
+}
+
+// Threshold scan of one block: every cell > powcut becomes a hit.
+__global__ __launch_bounds__(256) void k_block_threshold(const float *__restrict__ blockpow,
+                                                        float powcut, int stage, int64_t col0,
+                                                        DevHit *__restrict__ hits,
+                                                        unsigned int *__restrict__ count,
+                                                        unsigned int max_hits)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int zi = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const float p = j < USELEN ? blockpow[(size_t) zi * USELEN + j] : 0.f;
+    const bool hit = j < USELEN && p > powcut;
+    const unsigned long long mask = __ballot(hit);
+    if (mask) {
+        unsigned int base = 0;
+        const int leader = __ffsll((long long) mask) - 1;
+        if (lane == leader)
+            base = atomicAdd(count, (unsigned int) __popcll(mask));
+        base = __shfl(base, leader);
+        if (hit) {
+            const unsigned int pos = base + (unsigned int) __popcll(mask & ((1ull << lane) - 1ull));
+            if (pos < max_hits)
+                hits[pos] = DevHit{p, ((uint32_t) stage << 16) | (uint32_t) zi, col0 + j};
+        }
+    }
+}
+
 } // namespace accelk

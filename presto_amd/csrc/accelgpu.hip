@@ -944,6 +944,128 @@ int accelgpu_summed_block(accelgpu_ctx *ctx, int block, int stage, float *powers
     return ACCELGPU_OK;
 }
 
+static int stage_of(int numharm)
+{
+    int st = 0;
+    for (int n = numharm; n > 1; n >>= 1)
+        st++;
+    return (1 << st) == numharm ? st : -1;
+}
+
+// Uploads a host block into the context's block buffer.
+static int upload_block(accelgpu_ctx *ctx, const float *powers)
+{
+    const size_t elems = (size_t) ctx->numz * ACCELGPU_USELEN;
+    int rc = dev_reserve(&ctx->d_tmp, &ctx->tmp_cap, elems, false, ctx->stream);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->d_tmp, powers, elems * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    return ACCELGPU_OK;
+}
+
+int accelgpu_fund_to_ffdotplane(accelgpu_ctx *ctx, const float *powers, int32_t rlo)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if ((rc = check_ready(ctx, false))) return rc;
+    const int64_t col = (int64_t) rlo * 2;
+    if (!powers || col < 0 || col + ACCELGPU_USELEN > ctx->setup.rlen) {
+        set_error("accelgpu_fund_to_ffdotplane: block at rlo=%d does not fit the plane", rlo);
+        return ACCELGPU_ERR_ARG;
+    }
+    HIPCHK(hipMemcpy2DAsync(ctx->d_plane + col, (size_t) ctx->setup.rlen * sizeof(float), powers,
+                            ACCELGPU_USELEN * sizeof(float), ACCELGPU_USELEN * sizeof(float),
+                            ctx->numz, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ACCELGPU_OK;
+}
+
+int accelgpu_inmem_add_ffdotpows(accelgpu_ctx *ctx, float *powers, int32_t rlo, int numharm,
+                                 int harmnum)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if ((rc = check_ready(ctx, false))) return rc;
+    const int st = stage_of(numharm);
+    if (!powers || st < 1 || st > 5 || harmnum < 1 || harmnum >= numharm || rlo < 0 ||
+        (int64_t) rlo * 2 + ACCELGPU_USELEN > ctx->setup.rlen) {
+        set_error("accelgpu_inmem_add_ffdotpows: bad numharm/harmnum/rlo (%d, %d, %d)", numharm,
+                  harmnum, rlo);
+        return ACCELGPU_ERR_ARG;
+    }
+    std::vector<int> zind(ctx->numz);
+    const double f = (double) harmnum / (double) numharm;
+    for (int zi = 0; zi < ctx->numz; zi++) {
+        const int zz = (int) ctx->setup.zlo + zi * 2;
+        zind[zi] = accelhost::index_from_z(accelhost::calc_required_z(f, zz), ctx->setup.zlo);
+    }
+    int *d_zind = nullptr;
+    HIPCHK(hipMalloc((void **) &d_zind, zind.size() * sizeof(int)));
+    HIPCHK(hipMemcpyAsync(d_zind, zind.data(), zind.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = upload_block(ctx, powers))) return rc;
+    hipLaunchKernelGGL(accelk::k_block_add_harm, dim3((ACCELGPU_USELEN + 255) / 256, ctx->numz),
+                       dim3(256), 0, ctx->stream, ctx->d_tmp, ctx->d_plane, ctx->setup.rlen, rlo, st,
+                       harmnum, d_zind);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(powers, ctx->d_tmp, (size_t) ctx->numz * ACCELGPU_USELEN * sizeof(float),
+                          hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(d_zind));
+    return ACCELGPU_OK;
+}
+
+int accelgpu_search_ffdotpows(accelgpu_ctx *ctx, const float *powers, int32_t rlo, int numharm,
+                              accelgpu_hit *hits, int64_t max_hits, int64_t *n_hits)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if ((rc = check_ready(ctx, false))) return rc;
+    const int st = stage_of(numharm);
+    if (!powers || !n_hits || (!hits && max_hits > 0) || st < 0 || st >= ctx->setup.numharmstages) {
+        set_error("accelgpu_search_ffdotpows: bad arguments (numharm %d)", numharm);
+        return ACCELGPU_ERR_ARG;
+    }
+    const int64_t bcol = (int64_t) rlo * 2;
+    for (;;) {
+        if ((rc = upload_block(ctx, powers))) return rc;
+        HIPCHK(hipMemsetAsync(ctx->d_count, 0, sizeof(unsigned int), ctx->stream));
+        const unsigned int cap = (unsigned int) std::min<size_t>(ctx->hits_cap, 0xFFFFFFFFu);
+        hipLaunchKernelGGL(accelk::k_block_threshold, dim3((ACCELGPU_USELEN + 255) / 256, ctx->numz),
+                           dim3(256), 0, ctx->stream, ctx->d_tmp, ctx->setup.powcut[st], st, bcol,
+                           ctx->d_hits, ctx->d_count, cap);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(ctx->h_count, ctx->d_count, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (*ctx->h_count <= ctx->hits_cap)
+            break;
+        if ((rc = reserve_hits(ctx, (size_t) *ctx->h_count + 1024))) return rc;
+    }
+    const size_t n = *ctx->h_count;
+    *n_hits = (int64_t) n;
+    if ((int64_t) n > max_hits) {
+        set_error("%zu hits but room for %lld: re-run with a larger buffer", n, (long long) max_hits);
+        return ACCELGPU_ERR_OVERFLOW;
+    }
+    if (n) {
+        HIPCHK(hipMemcpyAsync(ctx->h_hits, ctx->d_hits, n * sizeof(DevHit), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    const int64_t rel = bcol - ctx->col0;
+    const int32_t block = (rel >= 0 && rel % ACCELGPU_USELEN == 0) ? (int32_t) (rel / ACCELGPU_USELEN) : -1;
+    for (size_t i = 0; i < n; i++) {
+        const DevHit &d = ctx->h_hits[i];
+        hits[i].power = d.power;
+        hits[i].stage = (int32_t) (d.stage_zind >> 16);
+        hits[i].zind = (int32_t) (d.stage_zind & 0xFFFF);
+        hits[i].rind = d.rind;
+        hits[i].block = block;
+    }
+    std::sort(hits, hits + n, [](const accelgpu_hit &a, const accelgpu_hit &b) {
+        if (a.zind != b.zind) return a.zind < b.zind;
+        return a.rind < b.rind;
+    });
+    return ACCELGPU_OK;
+}
+
 static int plane_span(accelgpu_ctx *ctx, int zind, int64_t col, int64_t count)
 {
     if (!ctx->have_search || !ctx->d_plane) {
