@@ -58,6 +58,7 @@ def main():
     import presto_amd as pa
     from presto_amd import synth
     from presto_amd.api import replay_candidates
+    from presto_amd import batch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -120,18 +121,9 @@ def main():
     t0 = time.perf_counter()
     results = run_steps(args.steps)
     if world > 1:
-        # merge candidate lists: fixed-size records, count first (RCCL over xGMI)
-        recs = np.concatenate([np.stack([c["r"], c["z"], c["sigma"].astype(np.float64),
-                                         c["numharm"].astype(np.float64)], axis=1)
-                               for _, c in results]) if results else np.zeros((0, 4))
-        cnt = torch.tensor([recs.shape[0]], device=dev, dtype=torch.int64)
-        cnts = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(cnts, cnt)
-        mx = int(max(int(c.item()) for c in cnts))
-        buf = torch.zeros((mx, 4), device=dev, dtype=torch.float64)
-        buf[:recs.shape[0]] = torch.from_numpy(recs).to(dev)
-        allb = [torch.zeros_like(buf) for _ in range(world)]
-        dist.all_gather(allb, buf)
+        # merge the per-trial candidate lists of all ranks (RCCL all-gather over xGMI)
+        recs = [batch.cands_to_records(rank * args.steps + i, c) for i, (_, c) in enumerate(results)]
+        merged = batch.merge_sorted(batch.allgather_records(np.concatenate(recs), dev))
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -1,0 +1,75 @@
+"""Multi-GPU partitioning and the candidate merge.
+
+The search shards without any data-path collective:
+  * a batch of DM trials: whole .fft files are dealt round-robin to ranks
+    (the reference runs one accelsearch process per file,
+    bin/GBNCC_search.py:360-413);
+  * one long series: contiguous ranges of the reference's search blocks
+    (startr = rlo + k*3735, src/accelsearch.c:165-218); a rank regenerates the
+    plane blocks its sub-harmonic look-ups fall in instead of receiving them.
+The only exchange is an all-gather of fixed-size candidate records (RCCL over
+xGMI when the tensors live on GPUs, gloo on CPU for tests).
+"""
+import numpy as np
+
+REC_FIELDS = ("trial", "r", "z", "sigma", "power", "numharm")
+
+
+def shard_trials(ntrials, rank, world):
+    """Indices of the DM trials rank `rank` searches."""
+    return list(range(rank, ntrials, world))
+
+
+def split_blocks(nblocks, world):
+    """Contiguous [first, last) ranges of search blocks, one per rank, sizes differing by <= 1."""
+    base, extra = divmod(nblocks, world)
+    out, first = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        out.append((first, first + n))
+        first += n
+    return out
+
+
+def cands_to_records(trial, cands):
+    """accelgpu candidate array -> float64 [n, 6] records (trial, r, z, sigma, power, numharm)."""
+    rec = np.empty((len(cands), len(REC_FIELDS)), dtype=np.float64)
+    rec[:, 0] = trial
+    rec[:, 1] = cands["r"]
+    rec[:, 2] = cands["z"]
+    rec[:, 3] = cands["sigma"]
+    rec[:, 4] = cands["power"]
+    rec[:, 5] = cands["numharm"]
+    return rec
+
+
+def allgather_records(records, device=None):
+    """All-gather of variable-length [n, 6] float64 record arrays over the default
+    torch.distributed group: counts first, then zero-padded fixed-size buffers.
+    Returns the concatenation in rank order (identical on every rank)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    dev = device if device is not None else torch.device("cpu")
+    records = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, len(REC_FIELDS))
+    cnt = torch.tensor([records.shape[0]], dtype=torch.int64, device=dev)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt)
+    counts = [int(c.item()) for c in cnts]
+    mx = max(max(counts), 1)
+    buf = torch.zeros((mx, len(REC_FIELDS)), dtype=torch.float64, device=dev)
+    if records.shape[0]:
+        buf[:records.shape[0]] = torch.from_numpy(records).to(dev)
+    bufs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf)
+    parts = [b[:n].cpu().numpy() for b, n in zip(bufs, counts)]
+    return np.concatenate(parts, axis=0) if parts else np.zeros((0, len(REC_FIELDS)))
+
+
+def merge_sorted(records):
+    """Cross-trial merged list, strongest first (ties by trial then r), as the
+    downstream sifting step expects to receive it."""
+    if len(records) == 0:
+        return records
+    order = np.lexsort((records[:, 1], records[:, 0], -records[:, 3]))
+    return records[order]

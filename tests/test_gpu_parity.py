@@ -243,3 +243,26 @@ def test_errors_are_reported(gpu):
     with pytest.raises(pa.AccelGPUError):
         g.fill_plane()                                      # nothing configured
     g.close()
+
+
+def test_golden_fixture(gpu):
+    """The committed golden vectors (tests/golden/search_small.npz): inputs plus the
+    oracle's hits, flags and candidates, checked without running the oracle."""
+    import os
+    import presto_amd as pa
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "search_small.npz"))
+    setup = gpu.configure(g["fft"].size, int(g["N"]), float(g["dt"]), int(g["zmax"]), int(g["numharm"]), fhi=1e9)
+    assert np.array_equal(np.array(list(setup.powcut)[:setup.numharmstages], dtype=np.float32), g["powcut"])
+    gpu.load_fft(g["fft"])
+    hits, cands, sig, added = gpu.search()
+    rel, edge_g, edge_w = _compare_lists(setup, hits, g["hits"])
+    assert len(rel) >= 0.99 * len(g["hits"]) and rel.max() <= 10 * PLANE_TOL
+    assert (edge_g <= 4 * PLANE_TOL).all() and (edge_w <= 4 * PLANE_TOL).all()
+    if len(edge_g) == 0 and len(edge_w) == 0:
+        assert np.array_equal(added, g["hits"]["added"])
+        assert np.array_equal(cands["r"], g["cands"]["r"]) and np.array_equal(cands["z"], g["cands"]["z"])
+        assert np.array_equal(cands["numharm"], g["cands"]["numharm"])
+    blk, rlo = gpu.subharm_ffdot_plane(float(g["rlo"]))
+    assert np.abs(blk[::5, ::37] - g["block0_rows"]).max() <= PLANE_TOL * g["block0_rows"].max()
+    k = gpu.kernel((int(g["zmax"]) + 10) // 2, setup.fftlen)
+    assert np.abs(k[::16] - g["kernel_z10"]).max() <= 4e-6 * np.abs(g["kernel_z10"]).max()

@@ -1,0 +1,169 @@
+"""CPU-only tests: the C ABI loads and exports what include/accelgpu.h declares,
+the host-side logic of the library (planning, detection statistics, candidate
+replay) agrees with the oracle, and the oracle reproduces its golden vectors."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "search_small.npz")
+
+
+def test_cabi_exports_every_declared_symbol():
+    import presto_amd as pa
+    hdr = open(os.path.join(ROOT, "include", "accelgpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(accelgpu_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(names) >= 25
+    lib = C.CDLL(pa.api.LIB_PATH)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert pa.load_library().accelgpu_version().decode().startswith("accelgpu")
+
+
+def test_struct_layouts_match_header():
+    import presto_amd as pa
+    assert C.sizeof(pa.api.Setup) == 8 * 4 + 4 * 8 + 8 * 6 + 4 + 4 * 6 + 4 + 8 * 6 + 16
+    assert pa.HIT_DTYPE.itemsize == 24 and pa.CAND_DTYPE.itemsize == 32
+
+
+@pytest.mark.parametrize("numbins,dt,zmax,numharm,flo,fhi,lobin", [
+    (524288, 1e-4, 0, 8, 1.0, 1e9, 0), (4194304, 64e-6, 200, 16, 1.0, 1e9, 0),
+    (67108864, 64e-6, 300, 16, 1.0, 1e9, 0), (8388608, 64e-6, 1200, 32, 1.0, 1e9, 0),
+    (100000, 1e-3, 51, 4, 0.5, 40.0, 0), (100000, 1e-3, 10, 1, 0.0, 1e9, 300)])
+def test_plan_matches_oracle(oracle, numbins, dt, zmax, numharm, flo, fhi, lobin):
+    import presto_amd as pa
+    p = pa.plan(numbins, 2 * numbins, dt, zmax, numharm, 2.0, flo, fhi, lobin)
+    o = oracle.Obs()
+    dummy = np.zeros(4, dtype=np.complex64)
+    assert oracle.lib().orc_obs_init(C.byref(o), dummy.ctypes.data_as(C.c_void_p), numbins,
+                                     2 * numbins, dt, zmax, numharm, 2.0, flo, fhi, lobin, 0, 0, 0) == 0
+    assert (p.rlo, p.rhi, p.highestbin, p.numz, p.fftlen, p.numharmstages, p.rlen, p.zmax) == \
+        (o.rlo, o.rhi, o.highestbin, o.numz, o.fftlen, o.numharmstages, o.rlen, o.zmax)
+    assert list(p.numindep)[:p.numharmstages] == list(o.numindep)[:o.numharmstages]
+    assert list(p.powcut)[:p.numharmstages] == list(o.powcut)[:o.numharmstages]
+    assert p.num_search_blocks == oracle.lib().orc_num_search_blocks(C.byref(o))
+    assert p.num_prepop_blocks == oracle.lib().orc_num_prepop_blocks(C.byref(o))
+
+
+def test_plan_rejects_what_the_reference_rejects():
+    import presto_amd as pa
+    for kw in (dict(numharm=3), dict(numharm=64), dict(flo=1e9), dict(lobin=10 ** 7)):
+        args = dict(numbins=1 << 16, N=1 << 17, dt=1e-3, zmax=20, numharm=8)
+        args.update(kw)
+        with pytest.raises(pa.AccelGPUError):
+            pa.plan(**args)
+    with pytest.raises(pa.AccelGPUError):                       # fhi below flo
+        pa.plan(1 << 16, 1 << 17, 1e-3, 20, 8, flo=50.0, fhi=10.0)
+    assert pa.plan(1 << 16, 1 << 17, 1e-3, 21, 8).zmax == 22    # odd zmax rounds up
+
+
+def test_sigma_functions_match_oracle(oracle):
+    import presto_amd.api as api
+    L = oracle.lib()
+    rng = np.random.default_rng(0)
+    for nh in (1, 2, 4, 8, 16, 32):
+        for nt in (1e3, 15236347.0, 5831448272.0):
+            assert api.power_for_sigma(2.0, nh, nt) == L.orc_power_for_sigma(2.0, nh, nt)
+            for pw in np.concatenate([rng.uniform(0.1 * nh, 40 * nh, 50), [0.0, -1.0, 15.0 * nh, 15.0001 * nh]]):
+                assert api.candidate_sigma(pw, nh, nt) == L.orc_candidate_sigma(float(pw), nh, nt)
+
+
+def test_oracle_reproduces_golden(oracle):
+    g = np.load(GOLD)
+    s = oracle.Search(g["fft"], int(g["N"]), float(g["dt"]), int(g["zmax"]), int(g["numharm"]), fhi=1e9)
+    assert np.array_equal(s.powcut, g["powcut"]) and np.array_equal(s.numindep, g["numindep"])
+    hits, cands = s.run()
+    assert len(hits) == len(g["hits"]) and len(cands) == len(g["cands"])
+    for f in ("numharm", "block", "zind", "rind", "added", "r", "z"):
+        assert np.array_equal(hits[f], g["hits"][f]), f
+    np.testing.assert_allclose(hits["power"], g["hits"]["power"], rtol=2e-6)
+    np.testing.assert_allclose(hits["sigma"], g["hits"]["sigma"], rtol=2e-5, atol=1e-5)
+    assert np.array_equal(cands["r"], g["cands"]["r"]) and np.array_equal(cands["z"], g["cands"]["z"])
+    blk, _ = s.fund_block(s.rlo)
+    np.testing.assert_allclose(blk[::5, ::37], g["block0_rows"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(oracle.init_kernel(10, s.fftlen)[0][::16], g["kernel_z10"], rtol=0, atol=1e-6)
+    s.close()
+
+
+def test_replay_matches_oracle_list(oracle):
+    """The library's array-based candidate replay against the oracle's linked
+    list, on the golden hit sequence and on adversarial synthetic sequences."""
+    import presto_amd as pa
+    from presto_amd.api import replay_candidates
+    g = np.load(GOLD)
+    setup = pa.plan(g["fft"].size, int(g["N"]), float(g["dt"]), int(g["zmax"]), int(g["numharm"]), fhi=1e9)
+    gh = g["hits"]
+    hits = np.zeros(len(gh), dtype=pa.HIT_DTYPE)
+    hits["power"], hits["zind"], hits["rind"], hits["block"] = gh["power"], gh["zind"], gh["rind"], gh["block"]
+    hits["stage"] = np.log2(gh["numharm"]).astype(np.int32)
+    cands, sig, added = replay_candidates(setup, hits)
+    assert np.array_equal(added, gh["added"])
+    assert np.array_equal(sig, gh["sigma"])
+    gc = g["cands"]
+    assert len(cands) == len(gc)
+    for f in ("r", "z", "numharm", "power", "sigma"):
+        assert np.array_equal(cands[f], gc[f]), f
+
+
+def test_replay_random_sequences_against_python_model():
+    """Independent pure-Python model of the list discipline (small cases)."""
+    import presto_amd as pa
+    from presto_amd.api import replay_candidates
+    setup = pa.plan(1 << 16, 1 << 17, 1e-3, 20, 8, fhi=1e9)
+    rng = np.random.default_rng(9)
+    for trial in range(20):
+        n = 300
+        hits = np.zeros(n, dtype=pa.HIT_DTYPE)
+        hits["stage"] = rng.integers(0, 4, n)
+        hits["zind"] = rng.integers(0, 21, n)
+        hits["rind"] = rng.integers(200, 3000, n)          # dense: lots of 15-bin collisions
+        hits["power"] = rng.uniform(20, 80, n).astype(np.float32)
+        cands, sig, added = replay_candidates(setup, hits)
+        lst = []                                            # [r, sigma, idx]
+        want_added = []
+        for i in range(n):
+            nh = 1 << int(hits["stage"][i])
+            rr = hits["rind"][i] * 0.5 / nh
+            s = sig[i]
+            a = 0
+            if not lst:
+                lst.append([rr, s, i]); a = 1
+            else:
+                cur = 0
+                while cur < len(lst) - 1 and lst[cur][0] < rr:
+                    cur += 1
+                nd = abs(rr - lst[cur][0])
+                pd = abs(rr - lst[cur - 1][0]) if cur > 0 else 16.0
+                if pd < 15.0:
+                    if lst[cur - 1][1] < s:
+                        lst[cur - 1] = [rr, s, i]; a = 1
+                    if nd < 15.0 and lst[cur][1] < s:
+                        if a:
+                            del lst[cur]
+                        else:
+                            lst[cur] = [rr, s, i]; a = 1
+                elif nd < 15.0:
+                    if lst[cur][1] < s:
+                        lst[cur] = [rr, s, i]; a = 1
+                else:
+                    a = 1
+                    if cur == len(lst) - 1 and lst[cur][0] < rr - 15.0:
+                        lst.append([rr, s, i])
+                    else:
+                        lst.insert(cur, [rr, s, i])
+            want_added.append(a)
+        assert np.array_equal(added, np.array(want_added))
+        assert [c for c in cands["added_order"]] == [e[2] for e in lst]
+
+
+def test_synthetic_inf_text_round_trip(tmp_path):
+    from presto_amd import synth
+    fft = synth.noise_fft(1024, 1)
+    synth.write_fft(str(tmp_path / "x"), fft, 2048, 1e-3)
+    assert os.path.getsize(tmp_path / "x.fft") == 1024 * 8
+    txt = open(tmp_path / "x.inf").read()
+    assert "Number of bins in the time series" in txt and "=  2048" in txt

@@ -1,0 +1,71 @@
+"""World-size-2 tests of the multi-rank path on CPU (gloo): trial sharding,
+block-range splitting and the all-gather merge of candidate records."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from presto_amd import batch
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, ntrials, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng_rows = []
+    for t in batch.shard_trials(ntrials, rank, world):
+        rng = np.random.default_rng(100 + t)
+        n = int(rng.integers(0, 6))
+        c = np.zeros(n, dtype=[("power", "f4"), ("sigma", "f4"), ("numharm", "i4"),
+                               ("added_order", "i4"), ("r", "f8"), ("z", "f8")])
+        c["r"], c["z"] = rng.uniform(10, 1e5, n), rng.integers(-100, 100, n) * 2.0
+        c["sigma"], c["power"], c["numharm"] = rng.uniform(2, 30, n), rng.uniform(20, 500, n), 1 << rng.integers(0, 5, n)
+        rng_rows.append(batch.cands_to_records(t, c))
+    local = np.concatenate(rng_rows) if rng_rows else np.zeros((0, 6))
+    merged = batch.merge_sorted(batch.allgather_records(local))
+    q.put((rank, merged))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_and_split():
+    assert batch.shard_trials(10, 1, 4) == [1, 5, 9]
+    assert sorted(sum((batch.shard_trials(1024, r, 8) for r in range(8)), [])) == list(range(1024))
+    r = batch.split_blocks(17965, 8)
+    assert r[0][0] == 0 and r[-1][1] == 17965 and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+    assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+    assert batch.split_blocks(3, 8)[3:] == [(3, 3)] * 5
+
+
+@pytest.mark.timeout(120)
+def test_allgather_merge_world2():
+    world, ntrials = 2, 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ntrials, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=100) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # every rank holds the same merged list, and it is what one process would build
+    assert np.array_equal(got[0], got[1])
+    rows = []
+    for t in range(ntrials):
+        rng = np.random.default_rng(100 + t)
+        n = int(rng.integers(0, 6))
+        rows.append(n)
+    assert got[0].shape == (sum(rows), 6)
+    assert set(got[0][:, 0].astype(int)) == {t for t, n in enumerate(rows) if n}
+    assert np.all(np.diff(got[0][:, 3]) <= 0)          # strongest first
