@@ -46,6 +46,10 @@ struct Twiddles {
     c32 *tw1 = nullptr, *tw2 = nullptr;
 };
 
+struct PowTables { // the two short tables of afft::TwoLevel, per thread column
+    c32 *pw1 = nullptr, *pw2 = nullptr;
+};
+
 struct EventPair {
     hipEvent_t a, b;
 };
@@ -60,6 +64,7 @@ struct accelgpu_ctx {
     int zmax = -1, numz = 0, fftlen = 0, halfwidth = 0;
     c32 *d_bank = nullptr;
     Twiddles tw_inv, tw_fwd_full, tw_fwd_half;
+    PowTables pw_inv;
 
     // spectrum
     const c32 *d_fft = nullptr;
@@ -163,6 +168,32 @@ template <class P> int make_twiddles(Twiddles *tw, int dir, hipStream_t st)
     return ACCELGPU_OK;
 }
 
+template <class P> int make_pow_tables(PowTables *pw, int dir, hipStream_t st)
+{
+    // rows: w^(4*hi), hi = 1..R/4-1, then w^lo, lo = 1..3 (see afft::TwoLevel)
+    const int n1 = P::R1 / 4 + 2, n2 = P::R2 / 4 + 2;
+    std::vector<c32> t1((size_t) n1 * P::M1), t2((size_t) n2 * P::R3);
+    auto expo = [](int row, int R) { return row < R / 4 - 1 ? 4 * (row + 1) : row - (R / 4 - 1) + 1; };
+    for (int k = 0; k < n1; k++)
+        for (int b = 0; b < P::M1; b++) {
+            const double a = dir * 2.0 * M_PI * (double) (((long long) b * expo(k, P::R1)) % P::N) / (double) P::N;
+            t1[(size_t) k * P::M1 + b] = c32{(float) std::cos(a), (float) std::sin(a)};
+        }
+    for (int k = 0; k < n2; k++)
+        for (int d = 0; d < P::R3; d++) {
+            const double a = dir * 2.0 * M_PI * (double) ((d * expo(k, P::R2)) % P::M1) / (double) P::M1;
+            t2[(size_t) k * P::R3 + d] = c32{(float) std::cos(a), (float) std::sin(a)};
+        }
+    if (pw->pw1) HIPCHK(hipFree(pw->pw1));
+    if (pw->pw2) HIPCHK(hipFree(pw->pw2));
+    HIPCHK(hipMalloc((void **) &pw->pw1, t1.size() * sizeof(c32)));
+    HIPCHK(hipMalloc((void **) &pw->pw2, t2.size() * sizeof(c32)));
+    HIPCHK(hipMemcpyAsync(pw->pw1, t1.data(), t1.size() * sizeof(c32), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(pw->pw2, t2.data(), t2.size() * sizeof(c32), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return ACCELGPU_OK;
+}
+
 template <class K> int allow_lds(K kernel, int bytes)
 {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
@@ -241,12 +272,34 @@ int launch_block_prep(accelgpu_ctx *ctx, int nblk, const int64_t *d_lobin, const
 int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const int64_t *d_col,
                      const int *d_ncols, float *d_plane, int64_t rlen)
 {
-    const int chunk = 8;
+    // Register-resident twiddle form: faster for the 8192-point plan (measured
+    // 4.45 vs 5.76 ms on cfg2); the 16384-point plan spills with it and stays on
+    // the table form (35.5 vs 41.9 ms).  ACCELGPU_CORR=0/1 forces one for A/B runs.
+    const char *variant = getenv("ACCELGPU_CORR");
+    const bool rr = variant ? atoi(variant) != 0 : ctx->fftlen == 8192;
+    int chunk = rr ? 16 : 8;
+    if (const char *e = getenv("ACCELGPU_CORR_CHUNK"))
+        chunk = std::max(1, atoi(e));
     const dim3 grid(ctx->numz, (nblk + chunk - 1) / chunk);
     EventPair ep;
     int rc = prof_begin(ctx, 1, &ep);
     if (rc) return rc;
-    if (ctx->fftlen == 8192) {
+    const int ser = getenv("ACCELGPU_CORR_SER") ? atoi(getenv("ACCELGPU_CORR_SER")) : 16;
+#define LAUNCH_RR(PLAN, SER)                                                                   \
+    hipLaunchKernelGGL((accelk::k_correlate_rr<PLAN, false, SER>), grid, dim3(PLAN::NT),       \
+                       PLAN::LDS_BYTES, ctx->stream, ctx->d_bank, d_blockfft, d_col, d_ncols,   \
+                       nblk, chunk, d_plane, rlen, ctx->halfwidth, ctx->pw_inv.pw1,            \
+                       ctx->pw_inv.pw2)
+    if (rr && ctx->fftlen == 8192) {
+        if (ser == 0) LAUNCH_RR(P8K, 0);
+        else if (ser == 32) LAUNCH_RR(P8K, 32);
+        else LAUNCH_RR(P8K, 16);
+    } else if (rr) {
+        if (ser == 0) LAUNCH_RR(P16K, 0);
+        else if (ser == 32) LAUNCH_RR(P16K, 32);
+        else LAUNCH_RR(P16K, 16);
+#undef LAUNCH_RR
+    } else if (ctx->fftlen == 8192) {
         hipLaunchKernelGGL((accelk::k_correlate<P8K, false>), grid, dim3(P8K::NT), P8K::LDS_BYTES,
                            ctx->stream, ctx->d_bank, d_blockfft, d_col, d_ncols, nblk, chunk,
                            d_plane, rlen, ctx->halfwidth, ctx->tw_inv.tw1, ctx->tw_inv.tw2);
@@ -505,6 +558,12 @@ int accelgpu_create(accelgpu_ctx **out, int device)
     if ((rc = allow_lds(accelk::k_block_prep<P8K>, P8K::LDS_BYTES + 64))) return rc;
     if ((rc = allow_lds(accelk::k_correlate<P8K, false>, P8K::LDS_BYTES))) return rc;
     if ((rc = allow_lds(accelk::k_correlate<P16K, false>, P16K::LDS_BYTES))) return rc;
+    if ((rc = allow_lds(accelk::k_correlate_rr<P8K, false, 0>, P8K::LDS_BYTES))) return rc;
+    if ((rc = allow_lds(accelk::k_correlate_rr<P8K, false, 16>, P8K::LDS_BYTES))) return rc;
+    if ((rc = allow_lds(accelk::k_correlate_rr<P8K, false, 32>, P8K::LDS_BYTES))) return rc;
+    if ((rc = allow_lds(accelk::k_correlate_rr<P16K, false, 0>, P16K::LDS_BYTES))) return rc;
+    if ((rc = allow_lds(accelk::k_correlate_rr<P16K, false, 16>, P16K::LDS_BYTES))) return rc;
+    if ((rc = allow_lds(accelk::k_correlate_rr<P16K, false, 32>, P16K::LDS_BYTES))) return rc;
     if ((rc = allow_lds(accelk::k_fft_rows<P8K, -1>, P8K::LDS_BYTES))) return rc;
     if ((rc = allow_lds(accelk::k_fft_rows<P16K, -1>, P16K::LDS_BYTES))) return rc;
     if ((rc = reserve_hits(ctx, (size_t) 1 << 20))) return rc;
@@ -521,7 +580,7 @@ void accelgpu_destroy(accelgpu_ctx *ctx)
     for (auto &v : ctx->ev)
         for (auto &e : v) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto &e : ctx->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-    void *dev[] = {ctx->d_bank, ctx->tw_inv.tw1, ctx->tw_inv.tw2, ctx->tw_fwd_full.tw1,
+    void *dev[] = {ctx->pw_inv.pw1, ctx->pw_inv.pw2, ctx->d_bank, ctx->tw_inv.tw1, ctx->tw_inv.tw2, ctx->tw_fwd_full.tw1,
                    ctx->tw_fwd_full.tw2, ctx->tw_fwd_half.tw1, ctx->tw_fwd_half.tw2,
                    ctx->d_fft_owned, ctx->d_blk_lobin, ctx->d_blk_col, ctx->d_blk_numdata,
                    ctx->d_blk_ncols, ctx->d_blockfft, ctx->d_plane, ctx->d_rowoff, ctx->d_rowchg, ctx->d_hits,
@@ -574,10 +633,12 @@ int accelgpu_build_kernels(accelgpu_ctx *ctx, int zmax)
     if (fftlen != ctx->fftlen) {
         if (fftlen == 8192) {
             if ((rc = make_twiddles<P8K>(&ctx->tw_inv, +1, ctx->stream))) return rc;
+            if ((rc = make_pow_tables<P8K>(&ctx->pw_inv, +1, ctx->stream))) return rc;
             if ((rc = make_twiddles<P8K>(&ctx->tw_fwd_full, -1, ctx->stream))) return rc;
             if ((rc = make_twiddles<P4K>(&ctx->tw_fwd_half, -1, ctx->stream))) return rc;
         } else {
             if ((rc = make_twiddles<P16K>(&ctx->tw_inv, +1, ctx->stream))) return rc;
+            if ((rc = make_pow_tables<P16K>(&ctx->pw_inv, +1, ctx->stream))) return rc;
             if ((rc = make_twiddles<P16K>(&ctx->tw_fwd_full, -1, ctx->stream))) return rc;
             if ((rc = make_twiddles<P8K>(&ctx->tw_fwd_half, -1, ctx->stream))) return rc;
         }

@@ -53,7 +53,9 @@ constexpr float kSin32[32] = {
 // In-register DFT of N = 2,4,...,32 points, natural order in and out:
 // v[k] <- sum_n v[n] * exp(DIR * 2*pi*i * n*k / N).  Everything is unrolled at
 // compile time so v[] lives in VGPRs.
-template <int N, int DIR> struct Dft {
+// SER: sizes >= SER run their two half-size sub-transforms one after the other
+// (scheduling barrier between them): fewer live temporaries, less overlap.  0 = off.
+template <int N, int DIR, int SER = 0> struct Dft {
     template <int K> static __device__ __forceinline__ void combine(c32 *v, const c32 *e, const c32 *o)
     {
         c32 t;
@@ -78,12 +80,16 @@ template <int N, int DIR> struct Dft {
             e[i] = v[2 * i];
             o[i] = v[2 * i + 1];
         }
-        Dft<N / 2, DIR>::run(e);
-        Dft<N / 2, DIR>::run(o);
+        Dft<N / 2, DIR, SER>::run(e);
+        if constexpr (SER > 0 && N >= SER)
+            __builtin_amdgcn_sched_barrier(0);
+        Dft<N / 2, DIR, SER>::run(o);
+        if constexpr (SER > 0 && N >= SER)
+            __builtin_amdgcn_sched_barrier(0);
         combine<0>(v, e, o);
     }
 };
-template <int DIR> struct Dft<2, DIR> {
+template <int DIR, int SER> struct Dft<2, DIR, SER> {
     static __device__ __forceinline__ void run(c32 *v)
     {
         const c32 a = v[0], b = v[1];
@@ -91,7 +97,7 @@ template <int DIR> struct Dft<2, DIR> {
         v[1] = a - b;
     }
 };
-template <int DIR> struct Dft<1, DIR> {
+template <int DIR, int SER> struct Dft<1, DIR, SER> {
     static __device__ __forceinline__ void run(c32 *) {}
 };
 
@@ -111,36 +117,82 @@ template <int R1_, int R2_, int R3_, int NT_> struct Plan {
     static_assert(B1 * R1 == E && B2 * R2 == E && B3 * R3 == E, "uneven split");
 };
 
-// One transform.  load(u, a, b) returns input element M1*a + b for the thread's
-// u-th pass-1 butterfly (u, a are compile-time after unrolling); store(n, v)
-// receives output n.  tw1: [R1][M1] table of exp(DIR*2*pi*i*b*n1/N); tw2:
-// [R2][R3] table of exp(DIR*2*pi*i*e*d/M1).  Ends with all LDS reads done but
-// no trailing barrier: callers that loop must __syncthreads() before reuse.
-template <class P, int DIR, class Load, class Store>
-__device__ __forceinline__ void fft3(c32 *lds, const c32 *__restrict__ tw1,
-                                     const c32 *__restrict__ tw2, Load load, Store store)
+// Twiddles from two short exact tables.  With n = 4*hi + lo, w^n = A[hi]*B[lo],
+// A[hi] = w^(4*hi) (hi = 1..R/4-1) and B[lo] = w^lo (lo = 1..3), all rounded from
+// double: every factor is exact or one product of two exact values.  A thread
+// keeps R/4+2 complex registers for the whole kernel instead of loading R-1
+// twiddles per transform.
+constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x / 2); }
+
+template <int R> struct TwoLevel {
+    static constexpr int NA = R / 4 - 1, NB = 3;
+    c32 A[NA], B[NB];
+};
+
+// Makes the register copies opaque to the optimiser at the point of call, so
+// products of table entries are formed where they are used (a handful of live
+// registers) instead of being hoisted out of the caller's loop (R-1 live values).
+template <int R> __device__ __forceinline__ void launder(TwoLevel<R> &w)
+{
+#pragma unroll
+    for (int k = 0; k < TwoLevel<R>::NA; k++) {
+        float x = w.A[k].x, y = w.A[k].y;
+        asm volatile("" : "+v"(x), "+v"(y));
+        w.A[k] = c32{x, y};
+    }
+#pragma unroll
+    for (int k = 0; k < TwoLevel<R>::NB; k++) {
+        float x = w.B[k].x, y = w.B[k].y;
+        asm volatile("" : "+v"(x), "+v"(y));
+        w.B[k] = c32{x, y};
+    }
+}
+
+template <int R> __device__ __forceinline__ void apply_twiddles_2level(c32 *v, const TwoLevel<R> &w)
+{
+#pragma unroll
+    for (int n = 1; n < R; n++) {
+        const int hi = n >> 2, lo = n & 3;
+        c32 t;
+        if (hi == 0)
+            t = w.B[lo - 1];
+        else if (lo == 0)
+            t = w.A[hi - 1];
+        else
+            t = cmul(w.A[hi - 1], w.B[lo - 1]);
+        v[n] = cmul(v[n], t);
+    }
+}
+
+// One transform, general form.  load(u, a, b) returns input element M1*a + b for
+// the thread's u-th pass-1 butterfly (u, a are compile-time after unrolling);
+// tw1(u, b, v) multiplies v[n1] by exp(DIR*2*pi*i*b*n1/N), n1 = 1..R1-1;
+// tw2(u, d, v) multiplies v[e] by exp(DIR*2*pi*i*e*d/M1), e = 1..R2-1;
+// mid() runs after the pass-1 LDS writes and before the first barrier (a place
+// to start global loads that should fly during passes 2 and 3);
+// store(n, v) receives output n.  Ends with all LDS reads done but no trailing
+// barrier: callers that loop must __syncthreads() before reuse.
+template <class P, int DIR, int SER = 0, class Load, class Tw1, class Tw2, class Mid, class Store>
+__device__ __forceinline__ void fft3x(c32 *lds, Load load, Tw1 tw1, Tw2 tw2, Mid mid, Store store)
 {
     const int t = threadIdx.x;
     c32 v[P::E];
 
-    // ---- pass 1 -------------------------------------------------------
 #pragma unroll
     for (int u = 0; u < P::B1; u++) {
         const int b = t + P::NT * u;
 #pragma unroll
         for (int a = 0; a < P::R1; a++)
             v[u * P::R1 + a] = load(u, a, b);
-        Dft<P::R1, DIR>::run(&v[u * P::R1]);
-#pragma unroll
-        for (int n1 = 1; n1 < P::R1; n1++)
-            v[u * P::R1 + n1] = cmul(v[u * P::R1 + n1], tw1[n1 * P::M1 + b]);
+        Dft<P::R1, DIR, SER>::run(&v[u * P::R1]);
+        tw1(u, b, &v[u * P::R1]);
 #pragma unroll
         for (int n1 = 0; n1 < P::R1; n1++)
             lds[n1 * P::S1 + b] = v[u * P::R1 + n1];
     }
+    mid();
     __syncthreads();
 
-    // ---- pass 2 -------------------------------------------------------
 #pragma unroll
     for (int u = 0; u < P::B2; u++) {
         const int g = t + P::NT * u;
@@ -154,17 +206,14 @@ __device__ __forceinline__ void fft3(c32 *lds, const c32 *__restrict__ tw1,
     for (int u = 0; u < P::B2; u++) {
         const int g = t + P::NT * u;
         const int d = g % P::R3, n1 = g / P::R3;
-        Dft<P::R2, DIR>::run(&v[u * P::R2]);
-#pragma unroll
-        for (int e = 1; e < P::R2; e++)
-            v[u * P::R2 + e] = cmul(v[u * P::R2 + e], tw2[e * P::R3 + d]);
+        Dft<P::R2, DIR, SER>::run(&v[u * P::R2]);
+        tw2(u, d, &v[u * P::R2]);
 #pragma unroll
         for (int e = 0; e < P::R2; e++)
             lds[(e * P::R3 + d) * P::S2 + n1] = v[u * P::R2 + e];
     }
     __syncthreads();
 
-    // ---- pass 3 -------------------------------------------------------
 #pragma unroll
     for (int u = 0; u < P::B3; u++) {
         const int g = t + P::NT * u;
@@ -172,11 +221,32 @@ __device__ __forceinline__ void fft3(c32 *lds, const c32 *__restrict__ tw1,
 #pragma unroll
         for (int d = 0; d < P::R3; d++)
             v[u * P::R3 + d] = lds[(e * P::R3 + d) * P::S2 + n1];
-        Dft<P::R3, DIR>::run(&v[u * P::R3]);
+        Dft<P::R3, DIR, SER>::run(&v[u * P::R3]);
 #pragma unroll
         for (int f = 0; f < P::R3; f++)
             store(g + P::R1 * P::R2 * f, v[u * P::R3 + f]);
     }
+}
+
+// Table form: tw1 is the [R1][M1] table of exp(DIR*2*pi*i*b*n1/N), tw2 the
+// [R2][R3] table of exp(DIR*2*pi*i*e*d/M1).
+template <class P, int DIR, class Load, class Store>
+__device__ __forceinline__ void fft3(c32 *lds, const c32 *__restrict__ tw1,
+                                     const c32 *__restrict__ tw2, Load load, Store store)
+{
+    fft3x<P, DIR>(
+        lds, load,
+        [&](int, int b, c32 *v) {
+#pragma unroll
+            for (int n1 = 1; n1 < P::R1; n1++)
+                v[n1] = cmul(v[n1], tw1[n1 * P::M1 + b]);
+        },
+        [&](int, int d, c32 *v) {
+#pragma unroll
+            for (int e = 1; e < P::R2; e++)
+                v[e] = cmul(v[e], tw2[e * P::R3 + d]);
+        },
+        [] {}, store);
 }
 
 } // namespace afft
