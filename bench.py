@@ -96,13 +96,16 @@ def main():
         return hits, cands
 
     def run_steps(k):
-        """k pipelined steps: the host replay of trial i overlaps the GPU work of i+1."""
+        """k pipelined steps: download, ordering and host replay of trial i overlap the
+        GPU work of trials i+1 and i+2 (two launches in flight, two hit buffers)."""
         out = []
         launch(0)
+        if k > 1:
+            launch(1)                      # two trials in flight: the GPU never waits for the host
         for i in range(k):
             hits = g.run_collect()
-            if i + 1 < k:
-                launch(i + 1)
+            if i + 2 < k:
+                launch(i + 2)
             cands, sig, added = replay_candidates(setup, hits)
             out.append((len(hits), cands))
         return out

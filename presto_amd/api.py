@@ -196,8 +196,6 @@ class AccelSearchGPU:
             rc = fn(self._h, _ptr(hits), max_hits, C.byref(n))
             if rc == -4 and n.value > max_hits:      # ACCELGPU_ERR_OVERFLOW: grow and repeat
                 max_hits = int(n.value * 1.25) + 1024
-                if fn is self.L.accelgpu_run_collect:
-                    fn = self.L.accelgpu_search_plane
                 continue
             _check(rc)
             return hits[:n.value]

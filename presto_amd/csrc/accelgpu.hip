@@ -92,12 +92,21 @@ struct accelgpu_ctx {
     size_t rowchg_cap = 0;
 
     // hits
+    // Two hit buffers so that one trial's hits can be collected while the next
+    // trial's kernels are already queued.  d_hits/h_hits/d_count/h_count alias
+    // the slot currently being launched into or collected from.
+    struct HitSlot {
+        DevHit *d_hits = nullptr, *h_hits = nullptr; // device buffer, pinned host mirror
+        unsigned int *d_count = nullptr, *h_count = nullptr;
+        hipEvent_t done = nullptr;                   // recorded after the slot's last copy
+        size_t prefetch = 0;                         // hits copied back speculatively at launch
+    } slots[2];
+    int head = 0, tail = 0, inflight = 0;            // FIFO of launched, uncollected trials
+    hipStream_t copy_stream = nullptr;               // late D2H copies that must not queue behind kernels
     DevHit *d_hits = nullptr;
-    DevHit *h_hits = nullptr; // pinned
+    DevHit *h_hits = nullptr;
     unsigned int *d_count = nullptr, *h_count = nullptr;
     size_t hits_cap = 0;
-    size_t prefetch_hits = 0; // hits copied back speculatively by run_launch
-    bool launched = false;
 
     // scratch for the single-block getters
     float *d_tmp = nullptr;
@@ -380,21 +389,36 @@ int launch_harmsum(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, 
     return launch_harmsum_j<DUMP, 0>(ctx, nstages, col0, ncols, dump, dump_stage);
 }
 
+void select_slot(accelgpu_ctx *ctx, int i)
+{
+    ctx->d_hits = ctx->slots[i].d_hits;
+    ctx->h_hits = ctx->slots[i].h_hits;
+    ctx->d_count = ctx->slots[i].d_count;
+    ctx->h_count = ctx->slots[i].h_count;
+}
+
 int reserve_hits(accelgpu_ctx *ctx, size_t want)
 {
     if (ctx->hits_cap >= want)
         return ACCELGPU_OK;
-    if (ctx->d_hits) HIPCHK(hipFree(ctx->d_hits));
-    if (ctx->h_hits) HIPCHK(hipHostFree(ctx->h_hits));
-    ctx->d_hits = nullptr;
-    ctx->h_hits = nullptr;
+    if (ctx->inflight > 0) {
+        set_error("cannot grow the hit buffers while %d launches are in flight", ctx->inflight);
+        return ACCELGPU_ERR_ARG;
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->hits_cap = 0;
-    if (hipMalloc((void **) &ctx->d_hits, want * sizeof(DevHit)) != hipSuccess ||
-        hipHostMalloc((void **) &ctx->h_hits, want * sizeof(DevHit)) != hipSuccess) {
-        set_error("cannot allocate room for %zu hits", want);
-        return ACCELGPU_ERR_NOMEM;
+    for (auto &sl : ctx->slots) {
+        if (sl.d_hits) HIPCHK(hipFree(sl.d_hits));
+        if (sl.h_hits) HIPCHK(hipHostFree(sl.h_hits));
+        sl.d_hits = sl.h_hits = nullptr;
+        if (hipMalloc((void **) &sl.d_hits, want * sizeof(DevHit)) != hipSuccess ||
+            hipHostMalloc((void **) &sl.h_hits, want * sizeof(DevHit)) != hipSuccess) {
+            set_error("cannot allocate room for %zu hits", want);
+            return ACCELGPU_ERR_NOMEM;
+        }
     }
     ctx->hits_cap = want;
+    select_slot(ctx, ctx->head);
     return ACCELGPU_OK;
 }
 
@@ -438,17 +462,28 @@ int queue_search(accelgpu_ctx *ctx)
     return ACCELGPU_OK;
 }
 
-// Waits for the queued search, re-running it with a larger buffer if the
-// compaction overflowed, then sorts into the reference's visiting order.
-int finish_search(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits, int64_t *n_hits)
+// Waits for the search launched into slot `si`, re-running it with a larger
+// buffer if the compaction overflowed (possible only when no later trial has
+// been queued, because the plane must still hold this trial), then sorts into
+// the reference's visiting order.
+int finish_search(accelgpu_ctx *ctx, int si, accelgpu_hit *hits, int64_t max_hits, int64_t *n_hits)
 {
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    size_t n = *ctx->h_count;
-    size_t have = ctx->prefetch_hits;
-    ctx->prefetch_hits = 0;
+    accelgpu_ctx::HitSlot &sl = ctx->slots[si];
+    select_slot(ctx, si);
+    HIPCHK(hipEventSynchronize(sl.done));
+    size_t n = *sl.h_count;
+    size_t have = std::min(sl.prefetch, n);
+    sl.prefetch = 0;
     if (n > ctx->hits_cap) {
+        if (ctx->inflight > 0) {
+            *n_hits = (int64_t) n;
+            set_error("%zu hits overflow the %zu-entry device buffer and a later trial is already "
+                      "queued: collect it, then run this trial again on its own", n, ctx->hits_cap);
+            return ACCELGPU_ERR_OVERFLOW;
+        }
         int rc = reserve_hits(ctx, n + n / 4 + 1024);
         if (rc) return rc;
+        select_slot(ctx, si);
         rc = queue_search(ctx);
         if (rc) return rc;
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -461,8 +496,8 @@ int finish_search(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits, int64
     }
     if (n > have) {
         HIPCHK(hipMemcpyAsync(ctx->h_hits + have, ctx->d_hits + have, (n - have) * sizeof(DevHit),
-                              hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+                              hipMemcpyDeviceToHost, ctx->copy_stream));
+        HIPCHK(hipStreamSynchronize(ctx->copy_stream));
     }
     *n_hits = (int64_t) n;
     if ((int64_t) n > max_hits) {
@@ -547,8 +582,12 @@ int accelgpu_create(accelgpu_ctx **out, int device)
     ctx->device = device;
     HIPCHK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
-    HIPCHK(hipMalloc((void **) &ctx->d_count, sizeof(unsigned int)));
-    HIPCHK(hipHostMalloc((void **) &ctx->h_count, sizeof(unsigned int)));
+    HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    for (auto &sl : ctx->slots) {
+        HIPCHK(hipMalloc((void **) &sl.d_count, sizeof(unsigned int)));
+        HIPCHK(hipHostMalloc((void **) &sl.h_count, sizeof(unsigned int)));
+        HIPCHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
     HIPCHK(hipMalloc((void **) &ctx->d_one_lobin, sizeof(int64_t)));
     HIPCHK(hipMalloc((void **) &ctx->d_one_col, sizeof(int64_t)));
     HIPCHK(hipMalloc((void **) &ctx->d_one_numdata, sizeof(int)));
@@ -567,6 +606,7 @@ int accelgpu_create(accelgpu_ctx **out, int device)
     if ((rc = allow_lds(accelk::k_fft_rows<P8K, -1>, P8K::LDS_BYTES))) return rc;
     if ((rc = allow_lds(accelk::k_fft_rows<P16K, -1>, P16K::LDS_BYTES))) return rc;
     if ((rc = reserve_hits(ctx, (size_t) 1 << 20))) return rc;
+    select_slot(ctx, 0);
     *out = ctx;
     return ACCELGPU_OK;
 }
@@ -583,13 +623,18 @@ void accelgpu_destroy(accelgpu_ctx *ctx)
     void *dev[] = {ctx->pw_inv.pw1, ctx->pw_inv.pw2, ctx->d_bank, ctx->tw_inv.tw1, ctx->tw_inv.tw2, ctx->tw_fwd_full.tw1,
                    ctx->tw_fwd_full.tw2, ctx->tw_fwd_half.tw1, ctx->tw_fwd_half.tw2,
                    ctx->d_fft_owned, ctx->d_blk_lobin, ctx->d_blk_col, ctx->d_blk_numdata,
-                   ctx->d_blk_ncols, ctx->d_blockfft, ctx->d_plane, ctx->d_rowoff, ctx->d_rowchg, ctx->d_hits,
-                   ctx->d_count, ctx->d_tmp, ctx->d_one_lobin, ctx->d_one_col,
+                   ctx->d_blk_ncols, ctx->d_blockfft, ctx->d_plane, ctx->d_rowoff, ctx->d_rowchg, ctx->d_tmp, ctx->d_one_lobin, ctx->d_one_col,
                    ctx->d_one_numdata, ctx->d_one_ncols, ctx->d_one_blockfft};
     for (void *p : dev)
         if (p) hipFree(p);
-    if (ctx->h_hits) hipHostFree(ctx->h_hits);
-    if (ctx->h_count) hipHostFree(ctx->h_count);
+    for (auto &sl : ctx->slots) {
+        if (sl.d_hits) hipFree(sl.d_hits);
+        if (sl.d_count) hipFree(sl.d_count);
+        if (sl.h_hits) hipHostFree(sl.h_hits);
+        if (sl.h_count) hipHostFree(sl.h_count);
+        if (sl.done) hipEventDestroy(sl.done);
+    }
+    if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -865,7 +910,6 @@ int accelgpu_set_search(accelgpu_ctx *ctx, const accelgpu_setup *s, int norm_typ
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->have_search = true;
-    ctx->launched = false;
     return ACCELGPU_OK;
 }
 
@@ -890,11 +934,19 @@ int accelgpu_search_plane(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hit
         set_error("accelgpu_search_plane: null output");
         return ACCELGPU_ERR_ARG;
     }
+    if (ctx->inflight > 0) {
+        set_error("accelgpu_search_plane: collect the %d launched trial(s) first", ctx->inflight);
+        return ACCELGPU_ERR_ARG;
+    }
     *n_hits = 0;
     if (ctx->nsearch == 0)
         return ACCELGPU_OK;
+    const int si = ctx->head;
+    select_slot(ctx, si);
+    ctx->slots[si].prefetch = 0;
     if ((rc = queue_search(ctx))) return rc;
-    return finish_search(ctx, hits, max_hits, n_hits);
+    HIPCHK(hipEventRecord(ctx->slots[si].done, ctx->stream));
+    return finish_search(ctx, si, hits, max_hits, n_hits);
 }
 
 int accelgpu_run_launch(accelgpu_ctx *ctx)
@@ -902,21 +954,26 @@ int accelgpu_run_launch(accelgpu_ctx *ctx)
     int rc = use(ctx);
     if (rc) return rc;
     if ((rc = check_ready(ctx, true))) return rc;
-    if (ctx->launched) {
-        set_error("accelgpu_run_launch: previous launch has not been collected");
+    if (ctx->inflight >= 2) {
+        set_error("accelgpu_run_launch: two launches are already in flight; collect one first");
         return ACCELGPU_ERR_ARG;
     }
-    ctx->prefetch_hits = 0;
+    const int si = ctx->tail;
+    accelgpu_ctx::HitSlot &sl = ctx->slots[si];
+    select_slot(ctx, si);
+    sl.prefetch = 0;
     if (ctx->nsearch > 0) {
         if ((rc = queue_fill(ctx))) return rc;
         if ((rc = queue_search(ctx))) return rc;
         // speculative copy of the head of the hit buffer: usually all of them
         const size_t pre = std::min<size_t>(ctx->hits_cap, 65536);
-        HIPCHK(hipMemcpyAsync(ctx->h_hits, ctx->d_hits, pre * sizeof(DevHit), hipMemcpyDeviceToHost,
+        HIPCHK(hipMemcpyAsync(sl.h_hits, sl.d_hits, pre * sizeof(DevHit), hipMemcpyDeviceToHost,
                               ctx->stream));
-        ctx->prefetch_hits = pre;
+        sl.prefetch = pre;
     }
-    ctx->launched = true;
+    HIPCHK(hipEventRecord(sl.done, ctx->stream));
+    ctx->tail ^= 1;
+    ctx->inflight++;
     return ACCELGPU_OK;
 }
 
@@ -924,7 +981,7 @@ int accelgpu_run_collect(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits
 {
     int rc = use(ctx);
     if (rc) return rc;
-    if (!ctx->launched) {
+    if (ctx->inflight == 0) {
         set_error("accelgpu_run_collect: nothing launched");
         return ACCELGPU_ERR_ARG;
     }
@@ -932,14 +989,23 @@ int accelgpu_run_collect(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits
         set_error("accelgpu_run_collect: null output");
         return ACCELGPU_ERR_ARG;
     }
-    ctx->launched = false;
+    const int si = ctx->head;
+    ctx->head ^= 1;
+    ctx->inflight--;
     *n_hits = 0;
-    if (ctx->nsearch == 0)
+    if (ctx->nsearch == 0) {
+        HIPCHK(hipEventSynchronize(ctx->slots[si].done));
         return ACCELGPU_OK;
-    size_t pre = ctx->prefetch_hits;
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->prefetch_hits = std::min<size_t>(pre, *ctx->h_count);
-    return finish_search(ctx, hits, max_hits, n_hits);
+    }
+    rc = finish_search(ctx, si, hits, max_hits, n_hits);
+    if (rc == ACCELGPU_ERR_OVERFLOW && *n_hits > max_hits && (size_t) *n_hits <= ctx->hits_cap) {
+        // the caller's buffer was too small; the hits are still in the slot's pinned
+        // mirror, so let a following accelgpu_search_plane() (plane intact) or a
+        // larger collect retry succeed: put the slot back
+        ctx->head = si;
+        ctx->inflight++;
+    }
+    return rc;
 }
 
 int accelgpu_run(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits, int64_t *n_hits)

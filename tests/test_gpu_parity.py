@@ -231,6 +231,19 @@ def test_async_launch_collect_equals_run(gpu):
     # a tiny caller buffer forces the overflow path and still returns every hit
     c = gpu.run(max_hits=1)
     assert np.array_equal(a, c)
+    # two launches in flight (double-buffered hits), collected in order
+    fft2 = synth.noise_fft(numbins, 12, lines=[(41000.5, 30.0, 10.0)])
+    gpu.load_fft(fft2)
+    b2 = gpu.run()
+    gpu.load_fft(fft)
+    gpu.run_launch()
+    gpu.load_fft(fft2)
+    gpu.run_launch()
+    with pytest.raises(Exception):
+        gpu.run_launch()                   # a third launch must be refused
+    assert np.array_equal(gpu.run_collect(), a)
+    assert np.array_equal(gpu.run_collect(), b2)
+    assert not np.array_equal(a, b2)
 
 
 def test_errors_are_reported(gpu):
