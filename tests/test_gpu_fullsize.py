@@ -1,0 +1,101 @@
+"""Full-size runs of the BASELINE configurations on the GPU, checked through
+size-independent properties (the CPU oracle would take minutes to hours here):
+  * injected drifting tones are recovered at their (r, z) with the injected power
+    and the right number of harmonics summed,
+  * hits come back in the reference's visiting order and a second run is identical,
+  * harmonic sums recomputed on the host from plane rows fetched through the C ABI
+    equal the device's sums bit for bit at sampled blocks (first, middle, last),
+  * the plane tiles the searched range without gaps (no cell of a searched column
+    is left at its zero fill).
+"""
+import numpy as np
+import pytest
+
+from presto_amd import synth
+
+pytestmark = pytest.mark.gpu
+USELEN = 7470
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import presto_amd as pa
+    g = pa.AccelSearchGPU(0)
+    yield g
+    g.close()
+
+
+def _host_sum(gpu, setup, block, stage):
+    """Sum the block's cells from plane rows exactly as inmem_add_ffdotpows does."""
+    rlo_b = int(setup.rlo) + block * 3735
+    rr = 2 * rlo_b + np.arange(USELEN, dtype=np.int64)
+    numz = setup.numz
+    zsel = np.unique(np.linspace(0, numz - 1, 5).astype(int))
+    out = {}
+    for zi in zsel:
+        acc = gpu.get_plane(zi, int(rr[0]), USELEN).copy()
+        zz = int(setup.zlo) + 2 * zi
+        for st in range(1, stage + 1):
+            n = 1 << st
+            for h in range(1, n, 2):
+                x = 0.5 * zz * h / n
+                subz = int(x - 0.5 if x < 0 else x + 0.5) * 2
+                zind = int((subz - setup.zlo) * 0.5 + 1e-14)
+                src = (rr * h + (n >> 1)) >> st
+                row = gpu.get_plane(zind, int(src[0]), int(src[-1] - src[0] + 1))
+                acc = acc + row[src - src[0]]
+        out[zi] = acc
+    return out
+
+
+def _check(gpu, numbins, dt, zmax, numharm, lines, seed):
+    fft = synth.noise_fft(numbins, seed, lines=lines)
+    setup = gpu.configure(numbins, 2 * numbins, dt, zmax, numharm, fhi=1e9)
+    gpu.load_fft(fft)
+    hits, cands, sig, added = gpu.search(max_hits=1 << 22)
+    # order: block, stage, zind, rind ascending
+    key = np.stack([hits["block"], hits["stage"], hits["zind"], hits["rind"]], axis=1).astype(np.int64)
+    assert np.all((np.diff(key, axis=0) != 0).argmax(axis=1) >= 0)
+    lex = np.lexsort((key[:, 3], key[:, 2], key[:, 1], key[:, 0]))
+    assert np.array_equal(lex, np.arange(len(hits)))
+    assert hits["block"].min() >= 0 and hits["block"].max() < setup.num_search_blocks
+    # every injected line is the strongest candidate near its frequency
+    for (r0, z0, amp) in lines:
+        near = cands[np.abs(cands["r"] - r0) < 8]
+        assert len(near) > 0, (r0, z0)
+        best = near[np.argmax(near["sigma"])]
+        assert abs(best["r"] - r0) <= 0.5 and abs(best["z"] - z0) <= 2.0, (best, r0, z0)
+        assert best["numharm"] == 1
+        assert 0.6 * amp * amp <= best["power"] <= 1.5 * amp * amp
+    # idempotence
+    hits2 = gpu.run(max_hits=1 << 22)
+    assert np.array_equal(hits, hits2)
+    # device sums == host sums from the same plane, bit for bit
+    nb = setup.num_search_blocks
+    for blk in sorted({0, nb // 2, nb - 1}):
+        st = setup.numharmstages - 1
+        dev = gpu.summed_block(blk, st)
+        for zi, acc in _host_sum(gpu, setup, blk, st).items():
+            assert np.array_equal(dev[zi].view(np.uint32), acc.view(np.uint32)), (blk, zi)
+        assert (gpu.summed_block(blk, 0) > 0).all()          # no gaps in the plane
+    return setup, hits, cands
+
+
+def test_cfg2_full_size(gpu):
+    # 2^23-point series (2^22 bins), zmax 200, numharm 16
+    _check(gpu, 1 << 22, 64e-6, 200, 16,
+           [(113443.25, 37.0, 14.0), (1701.5, 0.0, 12.0), (761215.0, -150.0, 16.0), (3999000.75, 198.0, 15.0)], 21)
+
+
+def test_cfg5_full_size(gpu):
+    # 2^24-point series, zmax 1200, numharm 32: 16384-point transforms, 80.7 GB plane
+    setup, hits, cands = _check(gpu, 1 << 23, 64e-6, 1200, 32,
+                                [(334651.5, 1100.0, 40.0), (61520.25, -420.0, 25.0), (7000000.0, -1190.0, 45.0)], 22)
+    assert setup.fftlen == 16384 and setup.numz == 1201 and setup.plane_bytes > 80e9
+
+
+def test_cfg4_full_size(gpu):
+    # 2^27-point series, zmax 300, numharm 16: 17965 search blocks, 161.6 GB plane on one GPU
+    setup, hits, cands = _check(gpu, 1 << 26, 64e-6, 300, 16,
+                                [(9.5e5 + 0.5, 290.0, 20.0), (3.1e7 + 0.25, -288.0, 20.0), (6.6e7, 10.0, 14.0)], 23)
+    assert setup.num_search_blocks == 17965 and setup.plane_bytes > 161e9
