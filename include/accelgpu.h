@@ -127,6 +127,19 @@ int accelgpu_load_fft_device(accelgpu_ctx *ctx, const void *fft_complex_dev, int
  * plane allocation src/accel_utils.c:1652-1670 (sized for HBM, not MAXRAMUSE). */
 int accelgpu_set_search(accelgpu_ctx *ctx, const accelgpu_setup *setup, int norm_type, float nph);
 
+/* One long series split over several GPUs: restricts this context to the search
+ * blocks [first_block, first_block + num_blocks) of the reference grid.  The
+ * following fill generates only the plane blocks those columns and their
+ * sub-harmonic look-ups (columns (int)(rind*h/n + 0.5), src/accel_utils.c:1174)
+ * fall in -- recomputed locally instead of exchanged -- and the search covers
+ * only those columns; hit block indices stay global.  *blocks_generated
+ * (optional) receives the number of plane blocks a fill will compute.
+ * accelgpu_set_search() resets the range to all blocks.
+ * ref: the loop bounds of src/accelsearch.c:165-168 (the reference has no
+ * counterpart; it searches the whole range in one process). */
+int accelgpu_set_block_range(accelgpu_ctx *ctx, int32_t first_block, int32_t num_blocks,
+                             int32_t *blocks_generated);
+
 /* Generates the whole fundamental plane: every pre-population block and every
  * search block of the reference grid (startr = 8 + k*3735 below rlo,
  * startr = rlo + k*3735 above).  ref: subharm_ffdot_plane(1,1,...) +

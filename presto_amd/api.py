@@ -77,6 +77,7 @@ def load_library():
     L.accelgpu_load_fft.argtypes = [vp, vp, i64]
     L.accelgpu_load_fft_device.argtypes = [vp, vp, i64]
     L.accelgpu_set_search.argtypes = [vp, pS, i, f]
+    L.accelgpu_set_block_range.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     L.accelgpu_fill_plane.argtypes = [vp]
     L.accelgpu_search_plane.argtypes = [vp, vp, i64, C.POINTER(i64)]
     L.accelgpu_run.argtypes = [vp, vp, i64, C.POINTER(i64)]
@@ -184,6 +185,13 @@ class AccelSearchGPU:
         self.create_subharminfos(self.setup.zmax)
         _check(self.L.accelgpu_set_search(self._h, C.byref(self.setup), 0, float(photon_nph)))
         return self.setup
+
+    def set_block_range(self, first_block, num_blocks):
+        """Search only blocks [first, first+num) of the grid (one long series split
+        over GPUs).  Returns the number of plane blocks a fill will generate."""
+        n = C.c_int32(0)
+        _check(self.L.accelgpu_set_block_range(self._h, int(first_block), int(num_blocks), C.byref(n)))
+        return n.value
 
     # -- the hot path -----------------------------------------------------
     def fill_plane(self):

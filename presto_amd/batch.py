@@ -73,3 +73,66 @@ def merge_sorted(records):
         return records
     order = np.lexsort((records[:, 1], records[:, 0], -records[:, 3]))
     return records[order]
+
+
+HIT_FIELDS = ("power", "stage", "zind", "block", "rind")
+
+
+def hits_to_records(hits):
+    """accelgpu hit array -> float64 [n, 5]: exact for float32 powers, small ints and
+    half-bin columns below 2^53."""
+    rec = np.empty((len(hits), len(HIT_FIELDS)), dtype=np.float64)
+    for i, f in enumerate(HIT_FIELDS):
+        rec[:, i] = hits[f]
+    return rec
+
+
+def records_to_hits(rec, dtype):
+    hits = np.zeros(len(rec), dtype=dtype)
+    hits["power"] = rec[:, 0].astype(np.float32)
+    for i, f in enumerate(HIT_FIELDS[1:], start=1):
+        hits[f] = rec[:, i].astype(hits.dtype[f])
+    return hits
+
+
+def reference_order(hits):
+    """Sort hits into the order the reference visits cells: block, stage, z row, r."""
+    order = np.lexsort((hits["rind"], hits["zind"], hits["stage"], hits["block"]))
+    return hits[order]
+
+
+def search_long_series(gpu, rank, world, max_hits=1 << 22, gather=None):
+    """One long series over `world` GPUs: rank searches its contiguous range of
+    search blocks (plane blocks it needs are regenerated locally), then the raw
+    hits are all-gathered and put back into the reference's order so that the
+    candidate list can be replayed exactly as a single process would.
+    `gather(records) -> records` defaults to the torch.distributed all-gather."""
+    first, last = split_blocks(gpu.setup.num_search_blocks, world)[rank]
+    gpu.set_block_range(first, last - first)
+    hits = gpu.run(max_hits)
+    rec = hits_to_records(hits)
+    if gather is None:
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+        allrec = _allgather_generic(rec, dev)
+    else:
+        allrec = gather(rec)
+    return reference_order(records_to_hits(allrec, hits.dtype))
+
+
+def _allgather_generic(rec, device):
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    dev = device if device is not None else torch.device("cpu")
+    ncol = rec.shape[1]
+    cnt = torch.tensor([rec.shape[0]], dtype=torch.int64, device=dev)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt)
+    counts = [int(c.item()) for c in cnts]
+    buf = torch.zeros((max(max(counts), 1), ncol), dtype=torch.float64, device=dev)
+    if rec.shape[0]:
+        buf[:rec.shape[0]] = torch.from_numpy(np.ascontiguousarray(rec)).to(dev)
+    bufs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf)
+    return np.concatenate([b[:n].cpu().numpy() for b, n in zip(bufs, counts)], axis=0)

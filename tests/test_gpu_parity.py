@@ -279,3 +279,34 @@ def test_golden_fixture(gpu):
     assert np.abs(blk[::5, ::37] - g["block0_rows"]).max() <= PLANE_TOL * g["block0_rows"].max()
     k = gpu.kernel((int(g["zmax"]) + 10) // 2, setup.fftlen)
     assert np.abs(k[::16] - g["kernel_z10"]).max() <= 4e-6 * np.abs(g["kernel_z10"]).max()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_block_range_split_equals_whole_search(gpu, world):
+    """One long series split into `world` block ranges (each regenerating the plane
+    blocks its look-ups need) gives, after merging, exactly the hits of one search."""
+    import presto_amd as pa
+    from presto_amd import batch
+    numbins = 1 << 18
+    fft = synth.noise_fft(numbins, 31, lines=[(20000.5, 12.0, 11.0), (150001.0, -40.0, 12.0), (4000.0, 0.0, 9.0)])
+    setup = gpu.configure(numbins, 2 * numbins, 1e-3, 60, 16, flo=0.3, fhi=1e9)
+    gpu.load_fft(fft)
+    whole = gpu.run()
+    total_blocks = setup.num_search_blocks + setup.num_prepop_blocks
+    parts, generated = [], []
+    for rank in range(world):
+        first, last = batch.split_blocks(setup.num_search_blocks, world)[rank]
+        # scribble over the plane so that nothing survives from the previous range
+        for z in (0, setup.numz // 2, setup.numz - 1):
+            gpu.put_plane(z, 0, np.full(setup.rlen, 1e9, dtype=np.float32))
+        generated.append(gpu.set_block_range(first, last - first))
+        parts.append(gpu.run())
+        if last > first:
+            assert parts[-1]["block"].min() >= first and parts[-1]["block"].max() < last
+    merged = batch.reference_order(np.concatenate(parts))
+    assert np.array_equal(merged, whole)
+    assert max(generated) <= total_blocks and generated[0] < total_blocks
+    # round trip through the record form used on the wire
+    assert np.array_equal(batch.records_to_hits(batch.hits_to_records(whole), whole.dtype), whole)
+    gpu.set_block_range(0, setup.num_search_blocks)
+    assert np.array_equal(gpu.run(), whole)

@@ -69,3 +69,58 @@ def test_allgather_merge_world2():
     assert got[0].shape == (sum(rows), 6)
     assert set(got[0][:, 0].astype(int)) == {t for t, n in enumerate(rows) if n}
     assert np.all(np.diff(got[0][:, 3]) <= 0)          # strongest first
+
+
+HIT_DTYPE = np.dtype([("power", "f4"), ("stage", "i4"), ("zind", "i4"), ("block", "i4"), ("rind", "i8")])
+
+
+def _fake_hits(nblocks, seed):
+    rng = np.random.default_rng(seed)
+    n = 500
+    h = np.zeros(n, dtype=HIT_DTYPE)
+    h["block"] = rng.integers(0, nblocks, n)
+    h["stage"] = rng.integers(0, 5, n)
+    h["zind"] = rng.integers(0, 201, n)
+    h["rind"] = 1072 + h["block"].astype(np.int64) * 7470 + rng.integers(0, 7470, n)
+    h["power"] = rng.uniform(20, 3000, n).astype(np.float32)
+    return batch.reference_order(h)
+
+
+def _range_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    allhits = _fake_hits(37, 5)
+    first, last = batch.split_blocks(37, world)[rank]
+    mine = allhits[(allhits["block"] >= first) & (allhits["block"] < last)]
+
+    class FakeGPU:                      # stands in for AccelSearchGPU on a CPU-only box
+        class setup:
+            num_search_blocks = 37
+
+        def set_block_range(self, a, n):
+            assert (a, n) == (first, last - first)
+
+        def run(self, max_hits):
+            return mine
+
+    merged = batch.search_long_series(FakeGPU(), rank, world)
+    q.put((rank, merged))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_long_series_hit_merge_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_range_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=100) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = _fake_hits(37, 5)
+    assert np.array_equal(got[0], want) and np.array_equal(got[1], want)
