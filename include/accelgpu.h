@@ -122,7 +122,8 @@ int accelgpu_load_fft_device(accelgpu_ctx *ctx, const void *fft_complex_dev, int
 /* Fixes the search geometry and thresholds.  `setup` comes from
  * accelgpu_plan() (or is filled by a host that ran create_accelobs() itself:
  * rlo, highestbin, lobin, zmax, numharmstages, powcut[] are what is read).
- * norm_type 0 = block median (default), nph > 0 selects -photon normalisation.
+ * norm_type 0 = block median (default), 1 = -locpow local-power normalisation
+ * (corr_loc_pow, src/corr_routines.c:309-366); nph > 0 selects -photon normalisation.
  * Allocates the in-HBM plane.  ref: accelobs fields, include/accel.h:33-71;
  * plane allocation src/accel_utils.c:1652-1670 (sized for HBM, not MAXRAMUSE). */
 int accelgpu_set_search(accelgpu_ctx *ctx, const accelgpu_setup *setup, int norm_type, float nph);

@@ -668,6 +668,40 @@ void orc_fund_block(const orc_obs *obs, double startr, float *powers, int *rlo_o
             data[ii].r *= norm;
             data[ii].i *= norm;
         }
+    } else if (obs->norm_type == 1) {                            /* :962-977 -locpow */
+        /* corr_loc_pow(), src/corr_routines.c:309-366: mean power in a ring of
+         * 10 + 10 bins at distance 6..15 (the FFT correlation there, scaled by
+         * 2/n twice over an integer-truncated kernel height, is this sum times
+         * (2/n)*((n/2)/20)); the first and last 15 values copy their neighbour;
+         * then the bit-trick inverse square root, src/misc_utils.c:255-266. */
+        const int n = nice_numdata, khw = 15;
+        float *pw = (float *) malloc(sizeof(float) * (size_t) n);
+        float *loc = (float *) malloc(sizeof(float) * (size_t) n);
+        const float scale = (2.0f / (float) n) * (float) ((n / 2) / 20);
+        for (int ii = 0; ii < n; ii++)
+            pw[ii] = data[ii].r * data[ii].r + data[ii].i * data[ii].i;
+        for (int ii = khw; ii < n - khw; ii++) {
+            float acc = 0.0f;
+            for (int k = -15; k <= -6; k++) acc += pw[ii + k];
+            for (int k = 6; k <= 15; k++) acc += pw[ii + k];
+            loc[ii] = acc * scale;
+        }
+        for (int ii = 0; ii < khw; ii++) {
+            loc[ii] = loc[khw];
+            loc[n - 1 - ii] = loc[n - 1 - khw];
+        }
+        for (int ii = 0; ii < numdata; ii++) {
+            const float x = loc[ii];
+            union { float f; int i; } u;
+            u.f = x;
+            u.i = 0x5f3759df - (u.i >> 1);
+            const float y = u.f;
+            const float nrm = y * (1.5f - 0.5f * x * y * y);
+            data[ii].r *= nrm;
+            data[ii].i *= nrm;
+        }
+        free(pw);
+        free(loc);
     } else {                                                     /* :949-961 block median */
         float *pw = (float *) malloc(sizeof(float) * (size_t) numdata);
         for (int ii = 0; ii < numdata; ii++)

@@ -179,11 +179,11 @@ class AccelSearchGPU:
         _check(self.L.accelgpu_load_fft_device(self._h, C.c_void_p(dev_ptr), int(numbins)))
 
     def configure(self, numbins, N, dt, zmax, numharm, sigma=2.0, flo=1.0, fhi=10000.0, lobin=0,
-                  photon_nph=0.0):
+                  photon_nph=0.0, norm_type=0):
         """plan + kernel bank + set_search in one call."""
         self.setup = plan(numbins, N, dt, zmax, numharm, sigma, flo, fhi, lobin)
         self.create_subharminfos(self.setup.zmax)
-        _check(self.L.accelgpu_set_search(self._h, C.byref(self.setup), 0, float(photon_nph)))
+        _check(self.L.accelgpu_set_search(self._h, C.byref(self.setup), int(norm_type), float(photon_nph)))
         return self.setup
 
     def set_block_range(self, first_block, num_blocks):

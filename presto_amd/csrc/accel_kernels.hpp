@@ -194,7 +194,7 @@ template <class P>
 __global__ __launch_bounds__(P::NT) void k_block_prep(
     const c32 *__restrict__ fft, int64_t numbins, int64_t file_lobin,
     const int64_t *__restrict__ blk_lobin, const int *__restrict__ blk_numdata,
-    c32 *__restrict__ blockfft, double nph_norm, const c32 *__restrict__ tw1,
+    c32 *__restrict__ blockfft, double nph_norm, int locpow, const c32 *__restrict__ tw1,
     const c32 *__restrict__ tw2)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -225,9 +225,41 @@ __global__ __launch_bounds__(P::NT) void k_block_prep(
         pw[a] = (idx < numdata) ? __float_as_uint(p) : 0xFFFFFFFFu;
     }
 
-    double norm;
+    double norm = 0.0;
     if (nph_norm > 0.0) {
         norm = nph_norm;
+    } else if (locpow) {
+        // -locpow: divide each bin by the root of the mean power in the ring of
+        // 10 + 10 bins at distance 6..15 (corr_loc_pow, reference
+        // src/corr_routines.c:309-366; the ends copy their nearest full value),
+        // through the same bit-trick inverse square root (src/misc_utils.c:255-266).
+        // Sums run in one fixed order and without fused ops, so the factors are
+        // reproducible bit for bit.
+        float *pl = reinterpret_cast<float *>(smem);
+#pragma unroll
+        for (int a = 0; a < P::R1; a++) {
+            const int idx = P::M1 * a + t;
+            pl[idx] = __fadd_rn(__fmul_rn(d[a].x, d[a].x), __fmul_rn(d[a].y, d[a].y));
+        }
+        __syncthreads();
+        const int n = P::N, khw = 15;
+        const float scale = __fmul_rn(2.0f / (float) n, (float) ((n / 2) / 20));
+#pragma unroll
+        for (int a = 0; a < P::R1; a++) {
+            const int idx = P::M1 * a + t;
+            if (idx < numdata) {
+                const int c = min(max(idx, khw), n - 1 - khw);
+                float acc = 0.0f;
+                for (int k = -15; k <= -6; k++) acc = __fadd_rn(acc, pl[c + k]);
+                for (int k = 6; k <= 15; k++) acc = __fadd_rn(acc, pl[c + k]);
+                const float x = __fmul_rn(acc, scale);
+                const float y = __int_as_float(0x5f3759df - (__float_as_int(x) >> 1));
+                const float nrm = __fmul_rn(y, __fsub_rn(1.5f, __fmul_rn(__fmul_rn(__fmul_rn(0.5f, x), y), y)));
+                d[a].x = __fmul_rn(d[a].x, nrm);
+                d[a].y = __fmul_rn(d[a].y, nrm);
+            }
+        }
+        __syncthreads(); // the FFT reuses this LDS
     } else {
         const int k = (numdata - 1) / 2;
         uint32_t prefix = 0;
@@ -255,12 +287,14 @@ __global__ __launch_bounds__(P::NT) void k_block_prep(
         const double med = (double) __uint_as_float(prefix);
         norm = 1.0 / sqrt(med / 0.69314718055994530942);
     }
+    if (!locpow || nph_norm > 0.0) {
 #pragma unroll
-    for (int a = 0; a < P::R1; a++) {
-        const int idx = P::M1 * a + t;
-        if (idx < numdata) {
-            d[a].x = (float) ((double) d[a].x * norm);
-            d[a].y = (float) ((double) d[a].y * norm);
+        for (int a = 0; a < P::R1; a++) {
+            const int idx = P::M1 * a + t;
+            if (idx < numdata) {
+                d[a].x = (float) ((double) d[a].x * norm);
+                d[a].y = (float) ((double) d[a].y * norm);
+            }
         }
     }
     __syncthreads();

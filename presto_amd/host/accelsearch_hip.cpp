@@ -1,0 +1,185 @@
+// accelsearch_hip -- command-line front end over libaccelgpu with the search
+// flags of PRESTO's accelsearch (reference clig/accelsearch_cmd.cli:13-47):
+//
+//   accelsearch_hip [-zmax Z] [-numharm H] [-sigma S] [-flo F] [-fhi F] [-lobin B]
+//                   [-photon] [-locpow] [-median] [-inmem] [-device D] file.fft
+//
+// Reads file.fft + file.inf, runs the Fourier-domain acceleration search on the
+// GPU and writes the working candidates file <root>_ACCEL_<zmax>.txtcand with the
+// reference's line format (src/accel_utils.c:1291-1294).  The search-time
+// candidate list (before optimisation, which this tool does not do) is printed
+// sorted by decreasing sigma (the ordering of src/accel_utils.c:278-298).
+// -rlo/-rhi are accepted and ignored, as in the reference (its parser marks
+// -flo/-fhi as always present, src/accelsearch_cmd.c:54-60).  The plane always
+// lives in HBM, so -inmem is implied.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "accelgpu.h"
+
+static void die(const char *what)
+{
+    printf("\n%s: %s\n\n", what, accelgpu_last_error());
+    exit(1);
+}
+
+// "<key text>  =  <value>" lines of a .inf file (reference src/ioinf.c:121-175)
+static bool inf_value(const std::string &path, const char *key, double *out)
+{
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f)
+        return false;
+    char line[512];
+    bool ok = false;
+    while (fgets(line, sizeof(line), f)) {
+        if (strstr(line, key)) {
+            const char *eq = strchr(line, '=');
+            if (eq) {
+                *out = atof(eq + 1);
+                ok = true;
+            }
+            break;
+        }
+    }
+    fclose(f);
+    return ok;
+}
+
+int main(int argc, char **argv)
+{
+    int zmax = 200, numharm = 8, device = 0, norm_type = 0;
+    long long lobin = 0;
+    double sigma = 2.0, flo = 1.0, fhi = 10000.0;
+    bool photon = false;
+    std::string infile;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto need = [&](const char *flag) {
+            if (i + 1 >= argc) {
+                printf("\nMissing value for %s\n\n", flag);
+                exit(1);
+            }
+            return argv[++i];
+        };
+        if (a == "-zmax") zmax = atoi(need("-zmax"));
+        else if (a == "-numharm") numharm = atoi(need("-numharm"));
+        else if (a == "-sigma") sigma = atof(need("-sigma"));
+        else if (a == "-flo") flo = atof(need("-flo"));
+        else if (a == "-fhi") fhi = atof(need("-fhi"));
+        else if (a == "-lobin") lobin = atoll(need("-lobin"));
+        else if (a == "-rlo" || a == "-rhi" || a == "-ncpus" || a == "-baryv") (void) need(a.c_str());
+        else if (a == "-device") device = atoi(need("-device"));
+        else if (a == "-photon") photon = true;
+        else if (a == "-locpow") norm_type = 1;
+        else if (a == "-median") norm_type = 0;
+        else if (a == "-inmem" || a == "-otheropt" || a == "-noharmpolish" || a == "-noharmremove") {}
+        else if (a[0] == '-') {
+            printf("\nUnknown option '%s'\n\n", a.c_str());
+            return 1;
+        } else infile = a;
+    }
+    if (infile.size() < 5 || infile.substr(infile.size() - 4) != ".fft") {
+        printf("\nInput file ('%s') must be an '.fft' file!\n\n", infile.c_str());
+        return 1;
+    }
+    if (zmax < 0 || zmax > 1200 || sigma < 1.0 || sigma > 30.0) {
+        printf("\n-zmax must be in 0..1200 and -sigma in 1..30\n\n");
+        return 1;
+    }
+    const std::string root = infile.substr(0, infile.size() - 4);
+    double Nd = 0, dt = 0;
+    if (!inf_value(root + ".inf", "Number of bins in the time series", &Nd) ||
+        !inf_value(root + ".inf", "Width of each time series bin", &dt)) {
+        printf("\nCannot read N and dt from '%s.inf'\n\n", root.c_str());
+        return 1;
+    }
+    FILE *f = fopen(infile.c_str(), "rb");
+    if (!f) {
+        perror(infile.c_str());
+        return 1;
+    }
+    fseek(f, 0, SEEK_END);
+    const long long numbins = ftell(f) / 8;
+    fseek(f, 0, SEEK_SET);
+    std::vector<float> fft((size_t) numbins * 2);
+    if (fread(fft.data(), 8, (size_t) numbins, f) != (size_t) numbins) {
+        printf("\nShort read on '%s'\n\n", infile.c_str());
+        return 1;
+    }
+    fclose(f);
+
+    printf("\n\n    Fourier-Domain Acceleration Search Routine (MI355X)\n\n");
+    const auto t0 = std::chrono::steady_clock::now();
+    accelgpu_setup su;
+    if (accelgpu_plan(numbins, (long long) Nd, dt, zmax, numharm, sigma, flo, fhi, lobin, &su))
+        die("accelgpu_plan");
+    printf("Searching with up to %d harmonics summed:\n", su.numharm);
+    printf("  f = %.1f to %.1f Hz\n", su.rlo / su.T, su.rhi / su.T);
+    printf("  r = %.1f to %.1f Fourier bins\n", su.rlo, su.rhi);
+    printf("  z = %.1f to %.1f Fourier bins drifted\n\n", su.zlo, su.zhi);
+    printf("Full f-fdot plane needs %.2f GB of HBM.\n\n", su.plane_bytes / 1073741824.0);
+
+    accelgpu_ctx *gpu = nullptr;
+    if (accelgpu_create(&gpu, device)) die("accelgpu_create");
+    if (accelgpu_build_kernels(gpu, su.zmax)) die("accelgpu_build_kernels");
+    printf("  Harmonic  1/1  has %3d kernel(s) from z = %4d to %4d,  FFT length = %d\n\n", su.numz,
+           -su.zmax, su.zmax, su.fftlen);
+    if (accelgpu_load_fft(gpu, fft.data(), numbins)) die("accelgpu_load_fft");
+    const float nph = (photon && lobin == 0) ? fft[0] : 0.f;
+    if (photon)
+        printf("Normalizing powers using %.0f photons.\n\n", nph);
+    if (accelgpu_set_search(gpu, &su, norm_type, nph)) die("accelgpu_set_search");
+
+    std::vector<accelgpu_hit> hits((size_t) 1 << 20);
+    int64_t nhits = 0;
+    int rc;
+    while ((rc = accelgpu_run(gpu, hits.data(), (int64_t) hits.size(), &nhits)) == ACCELGPU_ERR_OVERFLOW)
+        hits.resize((size_t) nhits + 1024);
+    if (rc) die("accelgpu_run");
+    std::vector<accelgpu_cand> cands((size_t) nhits + 1);
+    std::vector<float> sig((size_t) nhits + 1);
+    std::vector<int32_t> added((size_t) nhits + 1);
+    int64_t ncands = 0;
+    if (accelgpu_replay_candidates(&su, hits.data(), nhits, cands.data(), (int64_t) cands.size(), &ncands,
+                                   sig.data(), added.data()))
+        die("accelgpu_replay_candidates");
+
+    char work[4096];
+    snprintf(work, sizeof(work), "%s_ACCEL_%d.txtcand", root.c_str(), su.zmax);
+    FILE *w = fopen(work, "w");
+    if (!w) {
+        perror(work);
+        return 1;
+    }
+    for (int64_t i = 0; i < nhits; i++)
+        if (added[i]) {
+            const int nh = 1 << hits[i].stage;
+            const double rr = hits[i].rind * 0.5 / nh, zz = (su.zlo + hits[i].zind * 2.0) / nh;
+            fprintf(w, "%-7.2f  %-7.4f  %-2d  %-14.4f  %-14.9f  %-10.4f\n", hits[i].power, sig[i], nh, rr,
+                    rr / su.T, zz);
+        }
+    fclose(w);
+    printf("  Working candidates in a test format are in '%s'.\n\n", work);
+
+    std::stable_sort(cands.begin(), cands.begin() + ncands, [](const accelgpu_cand &a, const accelgpu_cand &b) {
+        if (a.sigma != b.sigma) return a.sigma > b.sigma;
+        return a.power > b.power;
+    });
+    printf("Found %lld candidates (%lld cells above threshold).  Strongest:\n", (long long) ncands,
+           (long long) nhits);
+    for (int64_t i = 0; i < std::min<int64_t>(ncands, 20); i++)
+        printf("sigma: %-7.4f  pow: %-7.2f  harm: %-2d  r: %-14.4f  z: %-10.4f\n", cands[i].sigma,
+               cands[i].power, cands[i].numharm, cands[i].r, cands[i].z);
+    printf("\nSearched the following approx numbers of independent points:\n");
+    for (int i = 0; i < su.numharmstages; i++)
+        printf("  %d harmonic%s  %9lld\n", 1 << i, i ? "s: " : ":  ", (long long) su.numindep[i]);
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("\nTiming summary:\n  Total time: %.3f sec\n\n", secs);
+    accelgpu_destroy(gpu);
+    return 0;
+}

@@ -310,3 +310,21 @@ def test_block_range_split_equals_whole_search(gpu, world):
     assert np.array_equal(batch.records_to_hits(batch.hits_to_records(whole), whole.dtype), whole)
     gpu.set_block_range(0, setup.num_search_blocks)
     assert np.array_equal(gpu.run(), whole)
+
+
+def test_locpow_normalisation(gpu, oracle):
+    """-locpow: local-power normalisation instead of the block median."""
+    fft, c = _case("cfg2", 1 << 18, 100, 8)
+    s = oracle.Search(fft, c["N"], c["dt"], 100, 8, fhi=1e9, norm_type=1, nthreads=8)
+    setup = gpu.configure(fft.size, c["N"], c["dt"], 100, 8, fhi=1e9, norm_type=1)
+    gpu.load_fft(fft)
+    for startr in (8.0, s.rlo, s.rlo + 3735.0 * (s.num_blocks - 1)):
+        want, _ = s.fund_block(startr)
+        got, _ = gpu.subharm_ffdot_plane(startr)
+        assert np.abs(got - want).max() <= PLANE_TOL * want.max()
+    want_hits, want_cands = s.run()
+    got_hits, got_cands, sig, added = gpu.search()
+    rel, edge_g, edge_w = _compare_lists(setup, got_hits, want_hits)
+    assert len(rel) >= 0.98 * len(want_hits) and rel.max() <= 10 * PLANE_TOL
+    assert (edge_g <= 4 * PLANE_TOL).all() and (edge_w <= 4 * PLANE_TOL).all()
+    s.close()

@@ -48,3 +48,37 @@ def test_shim_main_loop_matches_batched_search(tmp_path):
         zz = (setup.zlo + hits["zind"][i] * 2.0) / nh
         want = "%-7.2f  %-7.4f  %-2d  %-14.4f  %-14.9f  %-10.4f" % (hits["power"][i], sig[i], nh, rr, rr / T, zz)
         assert line == want
+
+
+def test_command_line_front_end(tmp_path):
+    """accelsearch_hip on .fft/.inf files: same work-file lines as the library path."""
+    import presto_amd as pa
+    exe = os.path.join(ROOT, "presto_amd", "host", "accelsearch_hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "-s"])
+    N, dt, zmax, numharm = 1 << 18, 5e-4, 51, 4          # odd zmax: rounded up to 52 like the reference
+    fft = synth.make_fft(N, dt, [dict(f=77.7, z=-31.0, amp=0.3, duty=0.05)], seed=8)
+    root = str(tmp_path / "trial_DM12.30")
+    synth.write_fft(root, fft, N, dt)
+    out = subprocess.check_output([exe, "-zmax", str(zmax), "-numharm", str(numharm), "-flo", "2.0",
+                                   "-fhi", "900", "-inmem", root + ".fft"], timeout=170).decode()
+    assert "FFT length = 8192" in out and "Searched the following approx numbers" in out
+    lines = open(root + "_ACCEL_52.txtcand").read().splitlines()
+    g = pa.AccelSearchGPU(0)
+    setup = g.configure(fft.size, N, dt, zmax, numharm, flo=2.0, fhi=900.0)
+    g.load_fft(fft)
+    hits, cands, sig, added = g.search()
+    g.close()
+    assert setup.zmax == 52 and len(lines) == int(added.sum()) > 0
+    T = N * dt
+    i = np.nonzero(added)[0][0]
+    nh = 1 << int(hits["stage"][i])
+    rr = hits["rind"][i] * 0.5 / nh
+    zz = (setup.zlo + hits["zind"][i] * 2.0) / nh
+    assert lines[0] == "%-7.2f  %-7.4f  %-2d  %-14.4f  %-14.9f  %-10.4f" % (hits["power"][i], sig[i], nh, rr, rr / T, zz)
+    best = cands[np.argmax(cands["sigma"])]
+    first = [l for l in out.splitlines() if l.startswith("sigma:")][0]
+    assert "r: %-14.4f" % best["r"] in first
+    # bad input is refused with the reference's message
+    bad = subprocess.run([exe, root + ".dat"], capture_output=True, text=True)
+    assert bad.returncode == 1 and "must be an '.fft' file" in bad.stdout
