@@ -189,6 +189,37 @@ int accelgpu_inmem_add_ffdotpows(accelgpu_ctx *ctx, float *powers, int32_t rlo, 
 int accelgpu_search_ffdotpows(accelgpu_ctx *ctx, const float *powers, int32_t rlo, int numharm,
                               accelgpu_hit *hits, int64_t max_hits, int64_t *n_hits);
 
+/* ---- standard (not in-memory) mode ----------------------------------------- */
+/* Same as accelgpu_set_search() but without the plane: for searches whose plane
+ * does not fit (the reference's rule is MAXRAMUSE, src/accel_utils.c:1652-1670)
+ * or hosts that keep the reference's default mode.  The in-memory entry points
+ * (fill/search/run, fund_to_ffdotplane, inmem_add_ffdotpows, the plane getters)
+ * then return ACCELGPU_ERR_ARG. */
+int accelgpu_set_search_standard(accelgpu_ctx *ctx, const accelgpu_setup *setup, int norm_type,
+                                 float nph);
+/* The F-Fdot block of harmonic harmnum/numharm for the fundamental columns
+ * fullrlo .. fullrhi (Fourier bins): own data window, own normalisation, own bank
+ * of templates (built on first use and cached per harmonic).  `powers` receives
+ * numzs*numrs floats, [z][r] (room for powers_cap floats; at most
+ * numz*(ACCELGPU_USELEN+2)); `rinds` (ACCELGPU_USELEN entries, may be NULL, not
+ * written for numharm 1) is the column look-up the reference stores in
+ * subharminfo.rinds.  ref: subharm_ffdot_plane(), src/accel_utils.c:879-1056;
+ * init_subharminfo(), :160-178. */
+int accelgpu_subharm_ffdot_plane(accelgpu_ctx *ctx, int numharm, int harmnum, double fullrlo,
+                                 double fullrhi, float *powers, int64_t powers_cap, int32_t *rlo,
+                                 int32_t *zlo, int32_t *numrs, int32_t *numzs, uint16_t *rinds);
+/* fund[z][j] += sub[zind(z)][rinds[j]] on the GPU; `fund` (numz*USELEN floats) is
+ * updated in place.  ref: add_ffdotpows(), src/accel_utils.c:1119-1134. */
+int accelgpu_add_ffdotpows(accelgpu_ctx *ctx, float *fund, const float *sub, int32_t sub_zlo,
+                           int32_t sub_numrs, int32_t sub_numzs, const uint16_t *rinds,
+                           int numharm, int harmnum);
+/* The whole main loop in standard mode, device resident: for every search block
+ * the fundamental, every sub-harmonic block, the adds and the threshold scans,
+ * batched over groups of blocks.  Hits as accelgpu_search_plane() returns them.
+ * ref: src/accelsearch.c:165-218 with obs.inmem == 0. */
+int accelgpu_run_standard(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits,
+                          int64_t *n_hits);
+
 /* ---- parity getters ------------------------------------------------------ */
 /* One fundamental block computed on its own: numz*USELEN floats, row-major
  * [z][r], exactly the ffdotpows.powers matrix.  ref: subharm_ffdot_plane(1,1,

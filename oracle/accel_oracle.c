@@ -641,27 +641,9 @@ static void fetch_amplitudes(const orc_obs *obs, long long lobin, int numbins, o
         memcpy(out + offset, obs->fft + firstbin, sizeof(orc_cf32) * (size_t) count);
 }
 
-/* subharm_ffdot_plane(1, 1, startr, startr + USELEN*DR - DR): :879-1056 */
-void orc_fund_block(const orc_obs *obs, double startr, float *powers, int *rlo_out)
+/* Normalisation of one data window, src/accel_utils.c:942-977. */
+static void normalise_window(const orc_obs *obs, orc_cf32 *data, int numdata, int nice_numdata)
 {
-    const double fullrhi = startr + ORC_USELEN * ORC_DR - ORC_DR;
-    const double drlo = orc_calc_required_r(1.0, startr);
-    const double drhi = orc_calc_required_r(1.0, fullrhi);
-    const int rlo = (int) floor(drlo);
-    const int numrs = ORC_USELEN;
-    const int numzs = obs->numz;
-    const int binoffset = obs->halfwidth;
-    const int fftlen = obs->fftlen;
-    const int lobin = rlo - binoffset;
-    const int hibin = (int) ceil(drhi) + binoffset;
-    const int numdata = hibin - lobin + 1;
-    const int nice_numdata = (int) orc_next2_to_n(numdata);
-
-    if (nice_numdata != fftlen / ORC_NUMBETWEEN)
-        printf("WARNING!!:  nice_numdata != fftlen/2 in orc_fund_block()!\n");
-    orc_cf32 *data = (orc_cf32 *) malloc(sizeof(orc_cf32) * (size_t) nice_numdata);
-    fetch_amplitudes(obs, lobin, nice_numdata, data);
-
     if (obs->nph > 0.0) {                                        /* :942-948 */
         const double norm = 1.0 / sqrt(obs->nph);
         for (int ii = 0; ii < numdata; ii++) {
@@ -713,6 +695,30 @@ void orc_fund_block(const orc_obs *obs, double startr, float *powers, int *rlo_o
             data[ii].i *= norm;
         }
     }
+}
+
+/* subharm_ffdot_plane(1, 1, startr, startr + USELEN*DR - DR): :879-1056 */
+void orc_fund_block(const orc_obs *obs, double startr, float *powers, int *rlo_out)
+{
+    const double fullrhi = startr + ORC_USELEN * ORC_DR - ORC_DR;
+    const double drlo = orc_calc_required_r(1.0, startr);
+    const double drhi = orc_calc_required_r(1.0, fullrhi);
+    const int rlo = (int) floor(drlo);
+    const int numrs = ORC_USELEN;
+    const int numzs = obs->numz;
+    const int binoffset = obs->halfwidth;
+    const int fftlen = obs->fftlen;
+    const int lobin = rlo - binoffset;
+    const int hibin = (int) ceil(drhi) + binoffset;
+    const int numdata = hibin - lobin + 1;
+    const int nice_numdata = (int) orc_next2_to_n(numdata);
+
+    if (nice_numdata != fftlen / ORC_NUMBETWEEN)
+        printf("WARNING!!:  nice_numdata != fftlen/2 in orc_fund_block()!\n");
+    orc_cf32 *data = (orc_cf32 *) malloc(sizeof(orc_cf32) * (size_t) nice_numdata);
+    fetch_amplitudes(obs, lobin, nice_numdata, data);
+
+    normalise_window(obs, data, numdata, nice_numdata);
 
     /* spread_no_pad + forward FFT: :980-983, src/corr_prep.c:3-40 */
     orc_cf32 *pdata = (orc_cf32 *) calloc((size_t) fftlen, sizeof(orc_cf32));
@@ -1027,4 +1033,160 @@ int orc_search_plane(orc_obs *obs, orc_hit *hits, long long max_hits, long long 
                      orc_cand *cands, int max_cands, int *n_cands)
 {
     return run_loop(obs, 1, hits, max_hits, n_hits, cands, max_cands, n_cands);
+}
+
+/* ------------------------------------------------------------------------
+ * Standard (not in-memory) mode: every sub-harmonic gets its own F-Fdot block
+ * from its own data window, its own median and its own kernel bank, and is added
+ * through the rinds/zinds look-up.  subharm_ffdot_plane() for any harmonic
+ * (src/accel_utils.c:879-1056), init_subharminfo() (:160-178), add_ffdotpows()
+ * (:1119-1134), and the non-inmem branch of the main loop
+ * (src/accelsearch.c:199-210).
+ * ---------------------------------------------------------------------- */
+typedef struct {
+    int numharm, harmnum, zmax, numkern, fftlen, halfwidth0;
+    orc_cf32 *kern;
+} sub_bank;
+
+#define ORC_MAXBANKS 64
+static sub_bank g_banks[ORC_MAXBANKS];
+static int g_nbanks = 0;
+
+static const sub_bank *get_bank(int numharm, int harmnum, int zmax_full)
+{
+    const double f = (double) harmnum / (double) numharm;
+    const int zmax = orc_calc_required_z(f, zmax_full);
+    const int fftlen = orc_calc_fftlen(numharm, harmnum, zmax_full);
+    for (int i = 0; i < g_nbanks; i++)
+        if (g_banks[i].numharm == numharm && g_banks[i].harmnum == harmnum &&
+            g_banks[i].zmax == zmax && g_banks[i].fftlen == fftlen)
+            return &g_banks[i];
+    if (g_nbanks == ORC_MAXBANKS)
+        g_nbanks = 0; /* recycle (leaks old kernels; test infrastructure) */
+    sub_bank *b = &g_banks[g_nbanks++];
+    b->numharm = numharm; b->harmnum = harmnum; b->zmax = zmax; b->fftlen = fftlen;
+    b->numkern = (zmax / ORC_DZ) * 2 + 1;
+    b->kern = (orc_cf32 *) malloc(sizeof(orc_cf32) * (size_t) b->numkern * (size_t) fftlen);
+    for (int ii = 0; ii < b->numkern; ii++) {
+        int hw;
+        orc_init_kernel(-zmax + ii * ORC_DZ, fftlen, b->kern + (size_t) ii * fftlen, &hw);
+        if (ii == 0)
+            b->halfwidth0 = hw;
+    }
+    return b;
+}
+
+/* powers must hold numzs*numrs floats (at most numz * (USELEN+2)); rinds USELEN shorts. */
+void orc_subharm_block(const orc_obs *obs, int numharm, int harmnum, double fullrlo,
+                       double fullrhi, float *powers, int *rlo_out, int *zlo_out, int *numrs_out,
+                       int *numzs_out, unsigned short *rinds)
+{
+    const sub_bank *bank = get_bank(numharm, harmnum, obs->zmax);
+    const double harm_fract = (double) harmnum / (double) numharm;
+    const double drlo = orc_calc_required_r(harm_fract, fullrlo);
+    const double drhi = orc_calc_required_r(harm_fract, fullrhi);
+    const int rlo = (int) floor(drlo);
+    const int zlo = orc_calc_required_z(harm_fract, obs->zlo);
+    if (numharm > 1 && rinds) {                               /* :910-917 */
+        for (int ii = 0; ii < ORC_USELEN; ii++) {
+            const double rr = fullrlo + ii * ORC_DR;
+            const double subr = orc_calc_required_r(harm_fract, rr);
+            rinds[ii] = (unsigned short) (int) ((subr - rlo) * ORC_RDR + ORC_DBLCORRECT);
+        }
+    }
+    int numrs = (int) ((ceil(drhi) - floor(drlo)) * ORC_RDR + ORC_DBLCORRECT) + 1; /* :919-927 */
+    if (numharm == 1 && harmnum == 1)
+        numrs = ORC_USELEN;
+    else if (numrs % ORC_RDR)
+        numrs = (numrs / ORC_RDR + 1) * ORC_RDR;
+    const int numzs = bank->numkern;
+    const int binoffset = bank->halfwidth0;
+    const int fftlen = bank->fftlen;
+    const int lobin = rlo - binoffset;
+    const int hibin = (int) ceil(drhi) + binoffset;
+    const int numdata = hibin - lobin + 1;
+    const int nice_numdata = (int) orc_next2_to_n(numdata);
+    if (nice_numdata != fftlen / ORC_NUMBETWEEN)
+        printf("WARNING!!:  nice_numdata != fftlen/2 in orc_subharm_block()!\n");
+    orc_cf32 *data = (orc_cf32 *) malloc(sizeof(orc_cf32) * (size_t) nice_numdata);
+    fetch_amplitudes(obs, lobin, nice_numdata, data);
+    normalise_window(obs, data, numdata, nice_numdata);
+    orc_cf32 *pdata = (orc_cf32 *) calloc((size_t) fftlen, sizeof(orc_cf32));
+    {
+        int numtoplace = fftlen / ORC_NUMBETWEEN;
+        if (numtoplace > nice_numdata) numtoplace = nice_numdata;
+        for (int ii = 0; ii < numtoplace; ii++)
+            pdata[ii * ORC_NUMBETWEEN] = data[ii];
+    }
+    orc_fft(pdata, fftlen, -1);
+    const float norm = 1.0 / ((double) fftlen * (double) fftlen);
+    const int offset = binoffset * ORC_NUMBETWEEN;
+    orc_cf32 *tmp = (orc_cf32 *) malloc(sizeof(orc_cf32) * (size_t) fftlen);
+    for (int zi = 0; zi < numzs; zi++) {
+        const orc_cf32 *k = bank->kern + (size_t) zi * fftlen;
+        for (int jj = 0; jj < fftlen; jj++) {
+            const float dr = pdata[jj].r, di = pdata[jj].i, kr = k[jj].r, ki = k[jj].i;
+            tmp[jj].r = dr * kr + di * ki;
+            tmp[jj].i = di * kr - dr * ki;
+        }
+        orc_fft(tmp, fftlen, +1);
+        float *out = powers + (size_t) zi * numrs;
+        for (int jj = 0; jj < numrs; jj++) {
+            const orc_cf32 v = tmp[jj + offset];
+            out[jj] = (v.r * v.r + v.i * v.i) * norm;
+        }
+    }
+    free(tmp); free(data); free(pdata);
+    *rlo_out = rlo; *zlo_out = zlo; *numrs_out = numrs; *numzs_out = numzs;
+}
+
+/* add_ffdotpows(), :1119-1134 */
+void orc_add_ffdotpows(const orc_obs *obs, float *fund, const float *sub, int sub_zlo,
+                       int sub_numrs, const unsigned short *rinds, int numharm, int harmnum)
+{
+    const double harm_fract = (double) harmnum / (double) numharm;
+    const int zlo = (int) obs->zlo;
+    for (int ii = 0; ii < obs->numz; ii++) {
+        const int zz = zlo + ii * ORC_DZ;
+        const int subz = orc_calc_required_z(harm_fract, zz);
+        const int zind = orc_index_from_z(subz, sub_zlo);
+        float *out = fund + (size_t) ii * ORC_USELEN;
+        const float *in = sub + (size_t) zind * sub_numrs;
+        for (int jj = 0; jj < ORC_USELEN; jj++)
+            out[jj] += in[rinds[jj]];
+    }
+}
+
+/* Main loop, standard branch (src/accelsearch.c:165-218 with obs.inmem == 0). */
+int orc_run_standard(orc_obs *obs, orc_hit *hits, long long max_hits, long long *n_hits,
+                     orc_cand *cands, int max_cands, int *n_cands)
+{
+    search_state st = { hits, max_hits, 0, NULL };
+    float *powers = (float *) malloc(sizeof(float) * (size_t) obs->numz * ORC_USELEN);
+    float *sub = (float *) malloc(sizeof(float) * (size_t) obs->numz * (ORC_USELEN + 2));
+    unsigned short *rinds = (unsigned short *) malloc(sizeof(unsigned short) * ORC_USELEN);
+    double startr = obs->rlo;
+    int block = 0;
+    while (startr + ORC_USELEN * ORC_DR < obs->highestbin) {
+        const double lastr = startr + ORC_USELEN * ORC_DR - ORC_DR;
+        int rlo, zlo, numrs, numzs;
+        orc_subharm_block(obs, 1, 1, startr, lastr, powers, &rlo, &zlo, &numrs, &numzs, NULL);
+        search_block(obs, powers, rlo, 1, block, &st);
+        for (int stage = 1; stage < obs->numharmstages; stage++) {
+            const int harmtosum = 1 << stage;
+            for (int harm = 1; harm < harmtosum; harm += 2) {
+                int srlo, szlo, snumrs, snumzs;
+                orc_subharm_block(obs, harmtosum, harm, startr, lastr, sub, &srlo, &szlo, &snumrs,
+                                  &snumzs, rinds);
+                orc_add_ffdotpows(obs, powers, sub, szlo, snumrs, rinds, harmtosum, harm);
+            }
+            search_block(obs, powers, rlo, harmtosum, block, &st);
+        }
+        startr += ORC_USELEN * ORC_DR;
+        block++;
+    }
+    free(powers); free(sub); free(rinds);
+    *n_hits = st.n_hits;
+    drain_list(&st, cands, max_cands, n_cands);
+    return 0;
 }

@@ -120,6 +120,15 @@ void orc_fill_plane(orc_obs *obs);
 int orc_search_plane(orc_obs *obs, orc_hit *hits, long long max_hits, long long *n_hits,
                      orc_cand *cands, int max_cands, int *n_cands);
 
+/* ---- standard (not in-memory) mode ---------------------------------------- */
+void orc_subharm_block(const orc_obs *obs, int numharm, int harmnum, double fullrlo,
+                       double fullrhi, float *powers, int *rlo_out, int *zlo_out, int *numrs_out,
+                       int *numzs_out, unsigned short *rinds);
+void orc_add_ffdotpows(const orc_obs *obs, float *fund, const float *sub, int sub_zlo,
+                       int sub_numrs, const unsigned short *rinds, int numharm, int harmnum);
+int orc_run_standard(orc_obs *obs, orc_hit *hits, long long max_hits, long long *n_hits,
+                     orc_cand *cands, int max_cands, int *n_cands);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,11 @@ def lib():
     L.orc_run.restype = i
     L.orc_search_plane.argtypes = L.orc_run.argtypes
     L.orc_search_plane.restype = i
+    L.orc_run_standard.argtypes = L.orc_run.argtypes
+    L.orc_run_standard.restype = i
+    pi = C.POINTER(i)
+    L.orc_subharm_block.argtypes = [C.POINTER(Obs), i, i, d, d, vp, pi, pi, pi, pi, vp]
+    L.orc_add_ffdotpows.argtypes = [C.POINTER(Obs), vp, vp, i, i, vp, i, i]
     L.orc_fill_plane.argtypes = [C.POINTER(Obs)]
     L.orc_num_search_blocks.argtypes = [C.POINTER(Obs)]; L.orc_num_search_blocks.restype = i
     L.orc_num_prepop_blocks.argtypes = [C.POINTER(Obs)]; L.orc_num_prepop_blocks.restype = i
@@ -247,6 +252,29 @@ class Search:
         """Full main loop: returns (hits in visit order, final candidate list)."""
         self.build_kernels()
         return self._collect(lib().orc_run, max_hits, max_cands)
+
+    def run_standard(self, max_hits=4_000_000, max_cands=200_000):
+        """Main loop in standard (not in-memory) mode."""
+        return self._collect(lib().orc_run_standard, max_hits, max_cands)
+
+    def subharm_block(self, numharm, harmnum, fullrlo, fullrhi=None):
+        """subharm_ffdot_plane for any harmonic: (powers[numzs, numrs], rlo, zlo, rinds)."""
+        if fullrhi is None:
+            fullrhi = fullrlo + USELEN * 0.5 - 0.5
+        buf = np.zeros(self.obs.numz * (USELEN + 2), dtype=np.float32)
+        rinds = np.zeros(USELEN, dtype=np.uint16)
+        rlo, zlo, numrs, numzs = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        lib().orc_subharm_block(C.byref(self.obs), numharm, harmnum, float(fullrlo), float(fullrhi),
+                                _ptr(buf), C.byref(rlo), C.byref(zlo), C.byref(numrs),
+                                C.byref(numzs), _ptr(rinds))
+        pw = buf[:numzs.value * numrs.value].reshape(numzs.value, numrs.value).copy()
+        return pw, rlo.value, zlo.value, rinds
+
+    def add_ffdotpows(self, fund, sub, sub_zlo, rinds, numharm, harmnum):
+        assert fund.dtype == np.float32 and fund.flags.c_contiguous
+        sub = np.ascontiguousarray(sub, dtype=np.float32)
+        lib().orc_add_ffdotpows(C.byref(self.obs), _ptr(fund), _ptr(sub), int(sub_zlo), sub.shape[1],
+                                _ptr(rinds), numharm, harmnum)
 
     def search_plane(self, max_hits=4_000_000, max_cands=200_000):
         """Harmonic sum + threshold + list insertion on the plane as it stands."""

@@ -86,6 +86,11 @@ def load_library():
     L.accelgpu_replay_candidates.argtypes = [pS, vp, i64, vp, i64, C.POINTER(i64), vp, vp]
     L.accelgpu_fund_block.argtypes = [vp, d, vp, C.POINTER(C.c_int32)]
     L.accelgpu_summed_block.argtypes = [vp, i, i, vp]
+    p32 = C.POINTER(C.c_int32)
+    L.accelgpu_set_search_standard.argtypes = [vp, pS, i, f]
+    L.accelgpu_subharm_ffdot_plane.argtypes = [vp, i, i, d, d, vp, i64, p32, p32, p32, p32, vp]
+    L.accelgpu_add_ffdotpows.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, i, i]
+    L.accelgpu_run_standard.argtypes = [vp, vp, i64, C.POINTER(i64)]
     L.accelgpu_get_plane.argtypes = [vp, i, i64, i64, vp]
     L.accelgpu_put_plane.argtypes = [vp, i, i64, i64, vp]
     L.accelgpu_set_profiling.argtypes = [vp, i]
@@ -179,11 +184,13 @@ class AccelSearchGPU:
         _check(self.L.accelgpu_load_fft_device(self._h, C.c_void_p(dev_ptr), int(numbins)))
 
     def configure(self, numbins, N, dt, zmax, numharm, sigma=2.0, flo=1.0, fhi=10000.0, lobin=0,
-                  photon_nph=0.0, norm_type=0):
-        """plan + kernel bank + set_search in one call."""
+                  photon_nph=0.0, norm_type=0, inmem=True):
+        """plan + kernel bank + set_search in one call.  inmem=False selects the
+        reference's standard mode (no plane; see run_standard)."""
         self.setup = plan(numbins, N, dt, zmax, numharm, sigma, flo, fhi, lobin)
         self.create_subharminfos(self.setup.zmax)
-        _check(self.L.accelgpu_set_search(self._h, C.byref(self.setup), int(norm_type), float(photon_nph)))
+        fn = self.L.accelgpu_set_search if inmem else self.L.accelgpu_set_search_standard
+        _check(fn(self._h, C.byref(self.setup), int(norm_type), float(photon_nph)))
         return self.setup
 
     def set_block_range(self, first_block, num_blocks):
@@ -226,6 +233,40 @@ class AccelSearchGPU:
         hits = self.run(max_hits)
         cands, sig, added = replay_candidates(self.setup, hits)
         return hits, cands, sig, added
+
+    # -- standard (not in-memory) mode ---------------------------------------
+    def run_standard(self, max_hits=1 << 20):
+        """Whole main loop without a plane: sorted hits."""
+        return self._hits_call(self.L.accelgpu_run_standard, max_hits)
+
+    def search_standard(self, max_hits=1 << 20):
+        hits = self.run_standard(max_hits)
+        cands, sig, added = replay_candidates(self.setup, hits)
+        return hits, cands, sig, added
+
+    def subharm_block(self, numharm, harmnum, fullrlo, fullrhi=None):
+        """subharm_ffdot_plane() for any harmonic:
+        (powers[numzs, numrs], rlo, zlo, rinds[USELEN] uint16)."""
+        if fullrhi is None:
+            fullrhi = fullrlo + USELEN * 0.5 - 0.5
+        cap = self.setup.numz * (USELEN + 2)
+        buf = np.empty(cap, dtype=np.float32)
+        rinds = np.zeros(USELEN, dtype=np.uint16)
+        rlo, zlo, numrs, numzs = (C.c_int32(0) for _ in range(4))
+        _check(self.L.accelgpu_subharm_ffdot_plane(
+            self._h, int(numharm), int(harmnum), float(fullrlo), float(fullrhi), _ptr(buf), cap,
+            C.byref(rlo), C.byref(zlo), C.byref(numrs), C.byref(numzs), _ptr(rinds)))
+        pw = buf[:numzs.value * numrs.value].reshape(numzs.value, numrs.value).copy()
+        return pw, rlo.value, zlo.value, rinds
+
+    def add_ffdotpows(self, fund, sub, sub_zlo, rinds, numharm, harmnum):
+        """fund[z][j] += sub[zind(z)][rinds[j]] in place (fund: float32 [numz, USELEN])."""
+        assert fund.dtype == np.float32 and fund.flags.c_contiguous
+        sub = np.ascontiguousarray(sub, dtype=np.float32)
+        rinds = np.ascontiguousarray(rinds, dtype=np.uint16)
+        _check(self.L.accelgpu_add_ffdotpows(self._h, _ptr(fund), _ptr(sub), int(sub_zlo),
+                                             sub.shape[1], sub.shape[0], _ptr(rinds),
+                                             int(numharm), int(harmnum)))
 
     # -- parity getters -----------------------------------------------------
     def subharm_ffdot_plane(self, startr):

@@ -187,6 +187,10 @@ __global__ __launch_bounds__(P::NT) void k_fft_rows(c32 *__restrict__ data,
 //             median by the -photon constant.
 //   forward : NF-point FFT.  The reference zero-interleaves to fftlen points
 //             first; that transform is this one repeated twice, X'[k] = X[k mod NF].
+// blk_nice[b] <= NF is the window length the reference reads
+// (next2_to_n(numdata)); a null pointer means NF.  It is shorter than NF only
+// for sub-harmonics whose reference transform is shorter than the shortest plan
+// here: those run zero-padded in a longer one.
 // The median is the exact order statistic (numdata-1)/2 (lower median), found
 // by a bitwise radix select on the IEEE bit patterns of the non-negative powers.
 // ---------------------------------------------------------------------------
@@ -194,8 +198,8 @@ template <class P>
 __global__ __launch_bounds__(P::NT) void k_block_prep(
     const c32 *__restrict__ fft, int64_t numbins, int64_t file_lobin,
     const int64_t *__restrict__ blk_lobin, const int *__restrict__ blk_numdata,
-    c32 *__restrict__ blockfft, double nph_norm, int locpow, const c32 *__restrict__ tw1,
-    const c32 *__restrict__ tw2)
+    c32 *__restrict__ blockfft, double nph_norm, int locpow, const int *__restrict__ blk_nice,
+    const c32 *__restrict__ tw1, const c32 *__restrict__ tw2)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     c32 *lds = reinterpret_cast<c32 *>(smem);
@@ -208,6 +212,7 @@ __global__ __launch_bounds__(P::NT) void k_block_prep(
     const int blk = blockIdx.x;
     const int64_t lobin = blk_lobin[blk];
     const int numdata = blk_numdata[blk];
+    const int nice_n = blk_nice ? blk_nice[blk] : P::N;
 
     c32 d[P::R1];
     uint32_t pw[P::R1];
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(P::NT) void k_block_prep(
         const int idx = P::M1 * a + t;
         const int64_t fbin = lobin + idx - file_lobin;
         c32 x = c32{0.f, 0.f};
-        if (fbin >= 0 && fbin < numbins)
+        if (fbin >= 0 && fbin < numbins && idx < nice_n)
             x = fft[fbin];
         d[a] = x;
         // r*r + i*i with each operation rounded on its own (no fma), so the
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(P::NT) void k_block_prep(
             pl[idx] = __fadd_rn(__fmul_rn(d[a].x, d[a].x), __fmul_rn(d[a].y, d[a].y));
         }
         __syncthreads();
-        const int n = P::N, khw = 15;
+        const int n = nice_n, khw = 15;
         const float scale = __fmul_rn(2.0f / (float) n, (float) ((n / 2) / 20));
 #pragma unroll
         for (int a = 0; a < P::R1; a++) {
@@ -664,6 +669,73 @@ __global__ __launch_bounds__(256) void k_block_threshold(const float *__restrict
             const unsigned int pos = base + (unsigned int) __popcll(mask & ((1ull << lane) - 1ull));
             if (pos < max_hits)
                 hits[pos] = DevHit{p, ((uint32_t) stage << 16) | (uint32_t) zi, col0 + j};
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// Standard (not in-memory) mode, batched over nb blocks.  Block matrices are
+// laid out [z][block][column] so that one correlate launch fills all blocks.
+// ---------------------------------------------------------------------------
+// rinds[b][j] = index_from_r(calc_required_r(f, startr_b + j/2), sub_rlo_b)
+// (reference src/accel_utils.c:910-917, 102-117), in fp64 with every operation
+// rounded on its own so the indices equal the host's.
+__global__ __launch_bounds__(256) void k_make_rinds(unsigned short *__restrict__ rinds,
+                                                   const double *__restrict__ startr,
+                                                   const int *__restrict__ sub_rlo,
+                                                   double harm_fract)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (j >= USELEN)
+        return;
+    const double rr = __dadd_rn(startr[b], __dmul_rn((double) j, 0.5));
+    const double t = __dadd_rn(__dmul_rn(__dmul_rn(2.0, rr), harm_fract), 0.5);
+    const double subr = __dmul_rn((double) (int) t, 0.5);
+    const double q = __dadd_rn(__dmul_rn(__dadd_rn(subr, -(double) sub_rlo[b]), 2.0), 1e-14);
+    rinds[(size_t) b * USELEN + j] = (unsigned short) (int) q;
+}
+
+// fund[zi][b][j] += sub[zind[zi]][b][rinds[b][j]]   (add_ffdotpows, :1119-1134)
+__global__ __launch_bounds__(256) void k_add_sub(float *__restrict__ fund,
+                                                const float *__restrict__ sub, int sub_stride,
+                                                const unsigned short *__restrict__ rinds,
+                                                const int *__restrict__ zind, int nb)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int zi = blockIdx.y, b = blockIdx.z;
+    if (j >= USELEN)
+        return;
+    const int src = rinds[(size_t) b * USELEN + j];
+    fund[((size_t) zi * nb + b) * USELEN + j] +=
+        sub[((size_t) zind[zi] * nb + b) * sub_stride + src];
+}
+
+// Threshold scan of nb blocks laid out [z][block][column].
+__global__ __launch_bounds__(256) void k_batch_threshold(const float *__restrict__ pow,
+                                                        float powcut, int stage,
+                                                        const int64_t *__restrict__ blk_col0,
+                                                        int nb, DevHit *__restrict__ hits,
+                                                        unsigned int *__restrict__ count,
+                                                        unsigned int max_hits)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int zi = blockIdx.y, b = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const float p = j < USELEN ? pow[((size_t) zi * nb + b) * USELEN + j] : 0.f;
+    const bool hit = j < USELEN && p > powcut;
+    const unsigned long long mask = __ballot(hit);
+    if (mask) {
+        unsigned int base = 0;
+        const int leader = __ffsll((long long) mask) - 1;
+        if (lane == leader)
+            base = atomicAdd(count, (unsigned int) __popcll(mask));
+        base = __shfl(base, leader);
+        if (hit) {
+            const unsigned int pos = base + (unsigned int) __popcll(mask & ((1ull << lane) - 1ull));
+            if (pos < max_hits)
+                hits[pos] = DevHit{p, ((uint32_t) stage << 16) | (uint32_t) zi, blk_col0[b] + j};
         }
     }
 }
