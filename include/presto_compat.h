@@ -63,6 +63,7 @@ typedef struct ffdotpows {                                    /* include/accel.h
 
 subharminfo **create_subharminfos(accelobs *obs);
 void free_subharminfos(accelobs *obs, subharminfo **shis);
+void add_ffdotpows(ffdotpows *fundamental, ffdotpows *subharmonic, int numharm, int harmnum);
 ffdotpows *subharm_ffdot_plane(int numharm, int harmnum, double fullrlo, double fullrhi,
                                subharminfo *shi, accelobs *obs);
 void fund_to_ffdotplane(ffdotpows *ffd, accelobs *obs);

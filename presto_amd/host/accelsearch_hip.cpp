@@ -2,7 +2,7 @@
 // flags of PRESTO's accelsearch (reference clig/accelsearch_cmd.cli:13-47):
 //
 //   accelsearch_hip [-zmax Z] [-numharm H] [-sigma S] [-flo F] [-fhi F] [-lobin B]
-//                   [-photon] [-locpow] [-median] [-inmem] [-device D] file.fft
+//                   [-photon] [-locpow] [-median] [-inmem] [-standard] [-device D] file.fft
 //
 // Reads file.fft + file.inf, runs the Fourier-domain acceleration search on the
 // GPU and writes the working candidates file <root>_ACCEL_<zmax>.txtcand with the
@@ -10,8 +10,10 @@
 // candidate list (before optimisation, which this tool does not do) is printed
 // sorted by decreasing sigma (the ordering of src/accel_utils.c:278-298).
 // -rlo/-rhi are accepted and ignored, as in the reference (its parser marks
-// -flo/-fhi as always present, src/accelsearch_cmd.c:54-60).  The plane always
-// lives in HBM, so -inmem is implied.
+// -flo/-fhi as always present, src/accelsearch_cmd.c:54-60).
+// Mode selection follows src/accel_utils.c:1652-1670 with HBM in place of
+// MAXRAMUSE: the in-memory search runs when the plane can be allocated (or
+// -inmem insists); otherwise, or with -standard, the standard search runs.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -55,7 +57,7 @@ int main(int argc, char **argv)
     int zmax = 200, numharm = 8, device = 0, norm_type = 0;
     long long lobin = 0;
     double sigma = 2.0, flo = 1.0, fhi = 10000.0;
-    bool photon = false;
+    bool photon = false, force_inmem = false, force_standard = false;
     std::string infile;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -77,7 +79,9 @@ int main(int argc, char **argv)
         else if (a == "-photon") photon = true;
         else if (a == "-locpow") norm_type = 1;
         else if (a == "-median") norm_type = 0;
-        else if (a == "-inmem" || a == "-otheropt" || a == "-noharmpolish" || a == "-noharmremove") {}
+        else if (a == "-inmem") force_inmem = true;
+        else if (a == "-standard") force_standard = true;
+        else if (a == "-otheropt" || a == "-noharmpolish" || a == "-noharmremove") {}
         else if (a[0] == '-') {
             printf("\nUnknown option '%s'\n\n", a.c_str());
             return 1;
@@ -122,7 +126,6 @@ int main(int argc, char **argv)
     printf("  f = %.1f to %.1f Hz\n", su.rlo / su.T, su.rhi / su.T);
     printf("  r = %.1f to %.1f Fourier bins\n", su.rlo, su.rhi);
     printf("  z = %.1f to %.1f Fourier bins drifted\n\n", su.zlo, su.zhi);
-    printf("Full f-fdot plane needs %.2f GB of HBM.\n\n", su.plane_bytes / 1073741824.0);
 
     accelgpu_ctx *gpu = nullptr;
     if (accelgpu_create(&gpu, device)) die("accelgpu_create");
@@ -133,14 +136,22 @@ int main(int argc, char **argv)
     const float nph = (photon && lobin == 0) ? fft[0] : 0.f;
     if (photon)
         printf("Normalizing powers using %.0f photons.\n\n", nph);
-    if (accelgpu_set_search(gpu, &su, norm_type, nph)) die("accelgpu_set_search");
+    printf("Full f-fdot plane would need %.2f GB: ", su.plane_bytes / 1073741824.0);
+    int rc = force_standard ? ACCELGPU_ERR_NOMEM : accelgpu_set_search(gpu, &su, norm_type, nph);
+    bool inmem = rc == ACCELGPU_OK;
+    if (rc == ACCELGPU_ERR_NOMEM && !force_inmem) {
+        if (accelgpu_set_search_standard(gpu, &su, norm_type, nph)) die("accelgpu_set_search_standard");
+    } else if (rc) {
+        die("accelgpu_set_search");
+    }
+    printf("using %s accelsearch.\n\n", inmem ? "in-memory" : "standard");
 
     std::vector<accelgpu_hit> hits((size_t) 1 << 20);
     int64_t nhits = 0;
-    int rc;
-    while ((rc = accelgpu_run(gpu, hits.data(), (int64_t) hits.size(), &nhits)) == ACCELGPU_ERR_OVERFLOW)
+    auto run = inmem ? accelgpu_run : accelgpu_run_standard;
+    while ((rc = run(gpu, hits.data(), (int64_t) hits.size(), &nhits)) == ACCELGPU_ERR_OVERFLOW)
         hits.resize((size_t) nhits + 1024);
-    if (rc) die("accelgpu_run");
+    if (rc) die(inmem ? "accelgpu_run" : "accelgpu_run_standard");
     std::vector<accelgpu_cand> cands((size_t) nhits + 1);
     std::vector<float> sig((size_t) nhits + 1);
     std::vector<int32_t> added((size_t) nhits + 1);

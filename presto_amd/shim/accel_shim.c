@@ -6,9 +6,10 @@
  *
  *   create_subharminfos   src/accel_utils.c:181-210   -> kernel bank on the GPU
  *   free_subharminfos     :225-244
- *   subharm_ffdot_plane   :879-1056   (numharm = harmnum = 1: in-memory search)
+ *   subharm_ffdot_plane   :879-1056   (any harmonic; the fundamental alone in -inmem runs)
  *   fund_to_ffdotplane    :1076-1090  -> plane lives in HBM
  *   inmem_add_ffdotpows   :1160-1208
+ *   add_ffdotpows         :1119-1134  (standard mode)
  *   search_ffdotpows      :1259-1299  (GPU threshold scan; sigma and the list stay on the host)
  *   free_ffdotpows        :1112-1117
  *
@@ -52,16 +53,46 @@ static int stage_of(int numharm)
     return st;
 }
 
-subharminfo **create_subharminfos(accelobs *obs)
+/* Host-side description of one harmonic: the fields accelsearch.c and the
+ * functions below read.  The FFT'd templates themselves live on the GPU. */
+static void describe_harmonic(int numharm, int harmnum, int zmax_full, subharminfo *shi)
 {
     int ii;
+    const double frac = (double) harmnum / (double) numharm;
+    const int fftlen = accelgpu_calc_fftlen(numharm, harmnum, zmax_full);
+    /* calc_required_z(): nearest even z of the scaled zmax */
+    const double zs = 0.5 * zmax_full * frac;
+    const int zmax = (int) (zs < 0 ? zs - 0.5 : zs + 0.5) * 2;
+
+    shi->numharm = numharm;
+    shi->harmnum = harmnum;
+    shi->zmax = zmax;
+    shi->numkern = (zmax / ACCEL_DZ) * 2 + 1;
+    shi->rinds = numharm > 1 ? (unsigned short *) malloc(ACCEL_USELEN * sizeof(unsigned short)) : NULL;
+    shi->kern = (kernel *) calloc(shi->numkern, sizeof(kernel));
+    for (ii = 0; ii < shi->numkern; ii++) {
+        kernel *k = &shi->kern[ii];
+        k->z = -zmax + ii * ACCEL_DZ;
+        k->fftlen = fftlen;
+        k->numbetween = 2;
+        k->kern_half_width = accelgpu_z_resp_halfwidth((double) k->z);
+        k->numgoodbins = k->fftlen - 4 * k->kern_half_width;
+        k->data = NULL;
+    }
+    if (numharm == 1)
+        printf("  Harmonic  1/1  has %3d kernel(s) from z = %4d to %4d,  FFT length = %d\n",
+               shi->numkern, -zmax, zmax, fftlen);
+    else
+        printf("  Harmonic %2d/%-2d has %3d kernel(s) from z = %4d to %4d,  FFT length = %d\n",
+               harmnum, numharm, shi->numkern, -zmax, zmax, fftlen);
+}
+
+subharminfo **create_subharminfos(accelobs *obs)
+{
+    int ii, jj;
     const int zmax = (int) obs->zhi;
     subharminfo **shis;
 
-    if (!obs->inmem) {
-        printf("\nThe GPU search keeps the full F-Fdot plane in HBM: run with -inmem semantics.\n\n");
-        exit(1);
-    }
     if (!obs->fft) {
         printf("\nThe GPU search needs the FFT in memory (mmap or .dat input).\n\n");
         exit(1);
@@ -93,34 +124,36 @@ subharminfo **create_subharminfos(accelobs *obs)
         g_setup.powcut[ii] = obs->powcut[ii];
         g_setup.numindep[ii] = obs->numindep[ii];
     }
-    if (accelgpu_set_search(g_ctx, &g_setup, obs->norm_type, obs->nph))
+    /* -inmem: the whole plane in HBM; otherwise per-harmonic blocks and no plane */
+    if (obs->inmem ? accelgpu_set_search(g_ctx, &g_setup, obs->norm_type, obs->nph)
+                   : accelgpu_set_search_standard(g_ctx, &g_setup, obs->norm_type, obs->nph))
         fail("accelgpu_set_search");
 
-    /* the host program only reads the fundamental's numkern/zmax/kern[0] fields */
     shis = (subharminfo **) malloc(obs->numharmstages * sizeof(subharminfo *));
     shis[0] = (subharminfo *) calloc(2, sizeof(subharminfo));
-    shis[0][0].numharm = 1;
-    shis[0][0].harmnum = 1;
-    shis[0][0].zmax = zmax;
-    shis[0][0].numkern = (zmax / ACCEL_DZ) * 2 + 1;
-    shis[0][0].kern = (kernel *) calloc(shis[0][0].numkern, sizeof(kernel));
-    for (ii = 0; ii < shis[0][0].numkern; ii++) {
-        kernel *k = &shis[0][0].kern[ii];
-        k->z = -zmax + ii * ACCEL_DZ;
-        k->fftlen = accelgpu_calc_fftlen(1, 1, zmax);
-        k->numbetween = 2;
-        k->kern_half_width = accelgpu_z_resp_halfwidth((double) k->z);
-        k->numgoodbins = k->fftlen - 4 * k->kern_half_width;
-        k->data = NULL; /* the FFT'd templates live on the GPU */
-    }
-    printf("  Harmonic  1/1  has %3d kernel(s) from z = %4d to %4d,  FFT length = %d\n",
-           shis[0][0].numkern, -zmax, zmax, shis[0][0].kern[0].fftlen);
+    describe_harmonic(1, 1, zmax, &shis[0][0]);
+    if (!obs->inmem)
+        for (ii = 1; ii < obs->numharmstages; ii++) {
+            const int harmtosum = 1 << ii;
+            shis[ii] = (subharminfo *) calloc(harmtosum, sizeof(subharminfo));
+            for (jj = 1; jj < harmtosum; jj += 2)
+                describe_harmonic(harmtosum, jj, zmax, &shis[ii][jj - 1]);
+        }
     return shis;
 }
 
 void free_subharminfos(accelobs *obs, subharminfo **shis)
 {
-    (void) obs;
+    int ii, jj;
+
+    if (!obs->inmem)
+        for (ii = 1; ii < obs->numharmstages; ii++) {
+            for (jj = 1; jj < (1 << ii); jj += 2) {
+                free(shis[ii][jj - 1].kern);
+                free(shis[ii][jj - 1].rinds);
+            }
+            free(shis[ii]);
+        }
     free(shis[0][0].kern);
     free(shis[0]);
     free(shis);
@@ -134,30 +167,38 @@ ffdotpows *subharm_ffdot_plane(int numharm, int harmnum, double fullrlo, double 
                                subharminfo *shi, accelobs *obs)
 {
     int ii;
-    int32_t rlo = 0;
+    int32_t rlo = 0, zlo = 0, numrs = 0, numzs = 0;
     ffdotpows *ffd;
     float *block;
+    const int64_t cap = (int64_t) obs->numz * (ACCEL_USELEN + 2);
 
-    (void) fullrhi;
-    (void) shi;
-    if (numharm != 1 || harmnum != 1) {
-        printf("subharm_ffdot_plane() on the GPU computes the fundamental only (in-memory search).\n");
+    if (numharm != 1 && obs->inmem) {
+        printf("subharm_ffdot_plane(): sub-harmonic blocks are not computed in an in-memory search.\n");
         printf("Exiting.\n\n");
         exit(0);
     }
     ffd = (ffdotpows *) malloc(sizeof(ffdotpows));
-    ffd->numrs = ACCEL_USELEN;
-    ffd->numzs = obs->numz;
-    ffd->zlo = (int) obs->zlo;
-    ffd->rinds = NULL;
-    block = (float *) malloc(sizeof(float) * (size_t) ffd->numzs * ffd->numrs);
+    block = (float *) malloc(sizeof(float) * (size_t) cap);
+    if (accelgpu_subharm_ffdot_plane(g_ctx, numharm, harmnum, fullrlo, fullrhi, block, cap, &rlo,
+                                     &zlo, &numrs, &numzs, numharm > 1 ? shi->rinds : NULL))
+        fail("accelgpu_subharm_ffdot_plane");
+    ffd->rlo = rlo;
+    ffd->zlo = zlo;
+    ffd->numrs = numrs;
+    ffd->numzs = numzs;
+    ffd->rinds = numharm > 1 ? shi->rinds : NULL;
     ffd->powers = (float **) malloc(sizeof(float *) * ffd->numzs);
     for (ii = 0; ii < ffd->numzs; ii++)
         ffd->powers[ii] = block + (size_t) ii * ffd->numrs;
-    if (accelgpu_fund_block(g_ctx, fullrlo, block, &rlo))
-        fail("accelgpu_fund_block");
-    ffd->rlo = rlo;
     return ffd;
+}
+
+void add_ffdotpows(ffdotpows *fundamental, ffdotpows *subharmonic, int numharm, int harmnum)
+{
+    if (accelgpu_add_ffdotpows(g_ctx, fundamental->powers[0], subharmonic->powers[0],
+                               subharmonic->zlo, subharmonic->numrs, subharmonic->numzs,
+                               subharmonic->rinds, numharm, harmnum))
+        fail("accelgpu_add_ffdotpows");
 }
 
 void free_ffdotpows(ffdotpows *ffd)

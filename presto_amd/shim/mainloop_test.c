@@ -1,8 +1,8 @@
 /*
  * mainloop_test.c -- drives the shim through the same call sequence as the
- * reference's search loop (src/accelsearch.c:116-224, in-memory branch) on a
- * .fft file, and prints the candidate list.  Test program only.
- *   usage: mainloop_test <file.fft> <N> <dt> <zmax> <numharm> <workfile>
+ * reference's search loop (src/accelsearch.c:116-224, in-memory or standard
+ * branch) on a .fft file, and prints the candidate list.  Test program only.
+ *   usage: mainloop_test <file.fft> <N> <dt> <zmax> <numharm> <workfile> [inmem=1]
  */
 #include <math.h>
 #include <stdio.h>
@@ -36,7 +36,7 @@ int main(int argc, char **argv)
     }
     obs.N = s.N; obs.numbins = numbins; obs.lobin = 0; obs.highestbin = s.highestbin;
     obs.fftlen = s.fftlen; obs.numharmstages = s.numharmstages; obs.numz = s.numz;
-    obs.numbetween = 2; obs.inmem = 1; obs.norm_type = 0; obs.mmap_file = 1;
+    obs.numbetween = 2; obs.inmem = argc > 7 ? atoi(argv[7]) : 1; obs.norm_type = 0; obs.mmap_file = 1;
     obs.dt = s.dt; obs.T = s.T; obs.rlo = s.rlo; obs.rhi = s.rhi; obs.dr = 0.5;
     obs.zlo = s.zlo; obs.zhi = s.zhi; obs.dz = 2; obs.sigma = s.sigma;
     obs.powcut = s.powcut; obs.numindep = (long long *) s.numindep;
@@ -46,7 +46,7 @@ int main(int argc, char **argv)
     GSList *cands = NULL;
     double startr, lastr, nextr;
     ffdotpows *fund;
-    for (startr = 8; startr < obs.rlo; startr = nextr) {     /* pre-population */
+    for (startr = 8; obs.inmem && startr < obs.rlo; startr = nextr) {     /* pre-population */
         nextr = startr + ACCEL_USELEN * ACCEL_DR;
         lastr = nextr - ACCEL_DR;
         fund = subharm_ffdot_plane(1, 1, startr, lastr, &shis[0][0], &obs);
@@ -59,11 +59,20 @@ int main(int argc, char **argv)
         fund = subharm_ffdot_plane(1, 1, startr, lastr, &shis[0][0], &obs);
         cands = search_ffdotpows(fund, 1, &obs, cands);
         if (obs.numharmstages > 1) {
-            fund_to_ffdotplane(fund, &obs);
+            if (obs.inmem)
+                fund_to_ffdotplane(fund, &obs);
             for (int stage = 1; stage < obs.numharmstages; stage++) {
                 const int harmtosum = 1 << stage;
-                for (int harm = 1; harm < harmtosum; harm += 2)
-                    inmem_add_ffdotpows(fund, &obs, harmtosum, harm);
+                for (int harm = 1; harm < harmtosum; harm += 2) {
+                    if (obs.inmem) {
+                        inmem_add_ffdotpows(fund, &obs, harmtosum, harm);
+                    } else {
+                        ffdotpows *sub = subharm_ffdot_plane(harmtosum, harm, startr, lastr,
+                                                             &shis[stage][harm - 1], &obs);
+                        add_ffdotpows(fund, sub, harmtosum, harm);
+                        free_ffdotpows(sub);
+                    }
+                }
                 cands = search_ffdotpows(fund, harmtosum, &obs, cands);
             }
         }

@@ -82,3 +82,47 @@ def test_command_line_front_end(tmp_path):
     # bad input is refused with the reference's message
     bad = subprocess.run([exe, root + ".dat"], capture_output=True, text=True)
     assert bad.returncode == 1 and "must be an '.fft' file" in bad.stdout
+
+
+def test_shim_main_loop_standard_mode(tmp_path):
+    """The reference's standard-mode call sequence through the shim (subharm_ffdot_plane
+    for every harmonic + add_ffdotpows) gives the candidates of accelgpu_run_standard."""
+    import presto_amd as pa
+    exe = os.path.join(ROOT, "presto_amd", "shim", "mainloop_test")
+    N, dt, zmax, numharm = 1 << 17, 1e-3, 20, 8
+    fft = synth.make_fft(N, dt, [dict(f=37.3, z=7.0, amp=0.35, duty=0.05)], seed=5)
+    root = str(tmp_path / "shimstd")
+    synth.write_fft(root, fft, N, dt)
+    out = subprocess.check_output([exe, root + ".fft", str(N), repr(dt), str(zmax), str(numharm),
+                                   root + ".txtcand", "0"], timeout=170).decode()
+    assert "Harmonic  3/8" in out
+    rows = [l.split()[1:] for l in out.splitlines() if l.startswith("CAND")]
+    shim = np.array([[float(x) for x in r] for r in rows])
+    g = pa.AccelSearchGPU(0)
+    g.configure(fft.size, N, dt, zmax, numharm, fhi=1e9, inmem=False)
+    g.load_fft(fft)
+    hits, cands, sig, added = g.search_standard()
+    g.close()
+    assert len(cands) == len(shim) > 0
+    assert np.array_equal(shim[:, 0].astype(np.float32), cands["power"])
+    assert np.array_equal(shim[:, 2].astype(int), cands["numharm"])
+    assert np.array_equal(shim[:, 3], cands["r"]) and np.array_equal(shim[:, 4], cands["z"])
+
+
+def test_command_line_standard_mode(tmp_path):
+    import presto_amd as pa
+    exe = os.path.join(ROOT, "presto_amd", "host", "accelsearch_hip")
+    N, dt, zmax, numharm = 1 << 18, 5e-4, 50, 8
+    fft = synth.make_fft(N, dt, [dict(f=77.7, z=-31.0, amp=0.3, duty=0.05)], seed=8)
+    root = str(tmp_path / "std_DM3.00")
+    synth.write_fft(root, fft, N, dt)
+    out = subprocess.check_output([exe, "-zmax", str(zmax), "-numharm", str(numharm), "-standard",
+                                   root + ".fft"], timeout=170).decode()
+    assert "using standard accelsearch" in out
+    lines = open(root + "_ACCEL_50.txtcand").read().splitlines()
+    g = pa.AccelSearchGPU(0)
+    g.configure(fft.size, N, dt, zmax, numharm, inmem=False)
+    g.load_fft(fft)
+    hits, cands, sig, added = g.search_standard()
+    g.close()
+    assert len(lines) == int(added.sum()) > 0
