@@ -118,6 +118,26 @@ int accelgpu_load_fft(accelgpu_ctx *ctx, const float *fft_complex_host, int64_t 
 /* Same, for a spectrum already in device memory (not copied, not owned). */
 int accelgpu_load_fft_device(accelgpu_ctx *ctx, const void *fft_complex_dev, int64_t numbins);
 
+/* Time-series input: uploads n float samples, transforms them on the device into
+ * the packed .fft layout (bin 0 = DC, Nyquist) and, if `deredden` is non-zero,
+ * removes red noise; the result becomes the current spectrum (numbins = n/2).
+ * n/2 must be a power of two (2^9..2^25); n <= 67108864 as in the reference.
+ * ref: the .dat branch of create_accelobs(), src/accel_utils.c:1429-1484;
+ * realfft(), src/fastffts.c:198-270; deredden(), src/accel_utils.c:1301-1374. */
+int accelgpu_load_dat(accelgpu_ctx *ctx, const float *series, int64_t n, int deredden);
+/* deredden() on the current spectrum in place (it must be library-owned:
+ * accelgpu_load_fft or accelgpu_load_dat).  ref: src/accel_utils.c:1301-1374. */
+int accelgpu_deredden(accelgpu_ctx *ctx);
+/* The stand-alone rednoise filter on the current spectrum in place: median
+ * blocks of startwidth*ln(bin) bins up to frequency endfreq (Hz), endwidth
+ * beyond; T = N*dt in seconds.  Reproduces the program's output file bin for
+ * bin, including its last half block, whose imaginary parts are written from
+ * the real parts.  ref: src/rednoise.c:57-188 (defaults 6, 100, 6.0:
+ * clig/rednoise_cmd.cli:13-21). */
+int accelgpu_rednoise(accelgpu_ctx *ctx, int startwidth, int endwidth, double endfreq, double T);
+/* Copies the current spectrum (numbins complex floats) to the host. */
+int accelgpu_get_fft(accelgpu_ctx *ctx, float *out_complex, int64_t numbins);
+
 /* ---- search ------------------------------------------------------------- */
 /* Fixes the search geometry and thresholds.  `setup` comes from
  * accelgpu_plan() (or is filled by a host that ran create_accelobs() itself:

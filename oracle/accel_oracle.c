@@ -1190,3 +1190,173 @@ int orc_run_standard(orc_obs *obs, orc_hit *hits, long long max_hits, long long 
     drain_list(&st, cands, max_cands, n_cands);
     return 0;
 }
+
+/* ------------------------------------------------------------------------
+ * Time-series input: realfft() (src/fastffts.c:198-270, forward direction) and
+ * deredden() (src/accel_utils.c:1301-1374), the two steps create_accelobs()
+ * applies to a .dat file (:1429-1484).
+ * ---------------------------------------------------------------------- */
+void orc_realfft_forward(float *idata, long n)
+{
+    const long nby2 = n >> 1;
+    orc_cf32 *data = (orc_cf32 *) idata;
+    const double cc = -0.5, theta = -6.2831853071795864769252867665590057683943387987502 / (double) n;
+    orc_fft(data, nby2, -1);
+    double wr = cos(theta), wi = sin(theta), tmp1 = sin(0.5 * theta);
+    const double wpr = -2.0 * tmp1 * tmp1, wpi = wi;
+    long il = 1, ih = nby2 - il;
+    for (; il <= (n >> 2); il++, ih--) {
+        const double h1r = 0.5 * (data[il].r + data[ih].r);
+        const double h1i = 0.5 * (data[il].i - data[ih].i);
+        const double h2r = -cc * (data[il].i + data[ih].i);
+        const double h2i = cc * (data[il].r - data[ih].r);
+        const double h2rwr = h2r * wr, h2rwi = h2r * wi, h2iwr = h2i * wr, h2iwi = h2i * wi;
+        data[il].r = h1r + h2rwr - h2iwi;
+        data[il].i = h1i + h2iwr + h2rwi;
+        data[ih].r = h1r - h2rwr + h2iwi;
+        data[ih].i = -h1i + h2iwr + h2rwi;
+        tmp1 = wr;
+        wr = tmp1 * wpr - wi * wpi + wr;
+        wi = wi * wpr + tmp1 * wpi + wi;
+    }
+    tmp1 = data[0].r;
+    data[0].r = tmp1 + data[0].i;
+    data[0].i = tmp1 - data[0].i;
+}
+
+/* invsqrtf(), src/misc_utils.c:255-266 */
+static float orc_invsqrtf(float x)
+{
+    union { float f; int i; } u;
+    u.f = x;
+    u.i = 0x5f3759df - (u.i >> 1);
+    const float y = u.f;
+    return y * (1.5f - 0.5f * x * y * y);
+}
+
+void orc_deredden(orc_cf32 *fft, int numamps)
+{
+    int ii, ind;
+    const int initialbuflen = 6, maxbuflen = 200;
+    int buflen, lastbuflen, binnum = 1, numwrote = 1;
+    float mean_old, mean_new, dslope = 1.0, norm;
+
+    fft[0].r = 1.0;
+    fft[0].i = 0.0;
+    float *powbuf = (float *) malloc(sizeof(float) * (size_t) numamps);
+    for (ii = 0; ii < numamps; ii++)
+        powbuf[ii] = fft[ii].r * fft[ii].r + fft[ii].i * fft[ii].i;
+    buflen = initialbuflen;
+    mean_old = orc_median(powbuf + binnum, buflen) / log(2.0);
+    norm = orc_invsqrtf(mean_old);
+    for (ind = numwrote; ind < binnum + buflen / 2; ind++) {
+        fft[ind].r *= norm;
+        fft[ind].i *= norm;
+    }
+    numwrote += buflen / 2;
+    binnum += buflen;
+    lastbuflen = buflen;
+    buflen = initialbuflen * log(binnum);
+    if (buflen > maxbuflen)
+        buflen = maxbuflen;
+    while (binnum + buflen < numamps) {
+        mean_new = orc_median(powbuf + binnum, buflen) / log(2.0);
+        dslope = (mean_new - mean_old) / (0.5 * (lastbuflen + buflen));
+        for (ii = 0, ind = numwrote; ind < binnum + buflen / 2; ii++, ind++) {
+            norm = orc_invsqrtf(mean_old + dslope * ii);
+            fft[ind].r *= norm;
+            fft[ind].i *= norm;
+        }
+        numwrote += ii;
+        binnum += buflen;
+        lastbuflen = buflen;
+        mean_old = mean_new;
+        buflen = initialbuflen * log(binnum);
+        if (buflen > maxbuflen)
+            buflen = maxbuflen;
+    }
+    for (ii = 0, ind = numwrote; ind < numamps; ii++, ind++) {
+        norm = orc_invsqrtf(mean_old + dslope * ii);
+        fft[ind].r *= norm;
+        fft[ind].i *= norm;
+    }
+    free(powbuf);
+}
+
+/* The stand-alone rednoise filter (src/rednoise.c:57-188) on an in-memory
+ * spectrum: same block walk as the program's read loop, output in place.  The
+ * program writes the imaginary parts of its last half block from the real
+ * parts (:176); so does this. */
+void orc_rednoise(orc_cf32 *fft, long numamps, int startwidth, int endwidth, double endfreq,
+                  double Tsec)
+{
+    const float T = (float) Tsec;
+    long binnum = 1, pos;
+    int bufflen = startwidth, nblk_old, nblk_new, mid_old, mid_new, ii, ind;
+    float mean_old, mean_new, dslope = 1.0, norm;
+    float *powbuf = (float *) malloc(sizeof(float) * 4096);
+    orc_cf32 *out = (orc_cf32 *) malloc(sizeof(orc_cf32) * (size_t) numamps);
+    long numwrote = 0, old_start;
+
+    out[0].r = 1.0; out[0].i = 0.0;
+    numwrote = 1;
+    pos = 1;
+    nblk_old = bufflen;
+    old_start = pos;
+    pos += nblk_old;
+    mid_old = nblk_old / 2;
+    for (ii = 0; ii < nblk_old; ii++)
+        powbuf[ii] = fft[old_start + ii].r * fft[old_start + ii].r + fft[old_start + ii].i * fft[old_start + ii].i;
+    mean_old = orc_median(powbuf, nblk_old) / log(2.0);
+    norm = orc_invsqrtf(mean_old);
+    for (ii = 0; ii < mid_old; ii++) {
+        out[numwrote + ii].r = fft[old_start + ii].r * norm;
+        out[numwrote + ii].i = fft[old_start + ii].i * norm;
+    }
+    numwrote += mid_old;
+    binnum += nblk_old;
+    bufflen = startwidth * log(binnum);
+    for (;;) {
+        nblk_new = bufflen;
+        if (pos + nblk_new > numamps)
+            nblk_new = (int) (numamps - pos);
+        if (nblk_new <= 0)
+            break;
+        const long new_start = pos;
+        pos += nblk_new;
+        mid_new = nblk_new / 2;
+        for (ii = 0; ii < nblk_new; ii++)
+            powbuf[ii] = fft[new_start + ii].r * fft[new_start + ii].r + fft[new_start + ii].i * fft[new_start + ii].i;
+        mean_new = orc_median(powbuf, nblk_new) / log(2.0);
+        dslope = (mean_new - mean_old) / (0.5 * (nblk_old + nblk_new));
+        for (ii = 0, ind = mid_old; ind < nblk_old; ii++, ind++) {
+            norm = orc_invsqrtf(mean_old + dslope * ii);
+            out[numwrote + ii].r = fft[old_start + ind].r * norm;
+            out[numwrote + ii].i = fft[old_start + ind].i * norm;
+        }
+        for (ind = 0; ind < mid_new; ii++, ind++) {
+            norm = orc_invsqrtf(mean_old + dslope * ii);
+            out[numwrote + ii].r = fft[new_start + ind].r * norm;
+            out[numwrote + ii].i = fft[new_start + ind].i * norm;
+        }
+        numwrote += ii;
+        binnum += nblk_new;
+        if ((float) binnum / T < endfreq)
+            bufflen = startwidth * log(binnum);
+        else
+            bufflen = endwidth;
+        old_start = new_start;
+        nblk_old = nblk_new;
+        mean_old = mean_new;
+        mid_old = mid_new;
+    }
+    for (ii = 0, ind = mid_old; ind < nblk_old; ii++, ind++) {
+        norm = orc_invsqrtf(mean_old + dslope * ii);
+        out[numwrote + ii].r = fft[old_start + ind].r * norm;
+        out[numwrote + ii].i = fft[old_start + ind].r * norm;
+    }
+    numwrote += nblk_old - mid_old;
+    memcpy(fft, out, sizeof(orc_cf32) * (size_t) numwrote);
+    free(out);
+    free(powbuf);
+}

@@ -129,6 +129,13 @@ void orc_add_ffdotpows(const orc_obs *obs, float *fund, const float *sub, int su
 int orc_run_standard(orc_obs *obs, orc_hit *hits, long long max_hits, long long *n_hits,
                      orc_cand *cands, int max_cands, int *n_cands);
 
+/* ---- time-series input ----------------------------------------------------- */
+/* In-place forward real FFT into PRESTO's packed layout (bin 0 = DC, Nyquist). */
+void orc_realfft_forward(float *idata, long n);
+void orc_deredden(orc_cf32 *fft, int numamps);
+void orc_rednoise(orc_cf32 *fft, long numamps, int startwidth, int endwidth, double endfreq,
+                  double Tsec);
+
 #ifdef __cplusplus
 }
 #endif

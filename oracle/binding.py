@@ -101,6 +101,9 @@ def lib():
     pi = C.POINTER(i)
     L.orc_subharm_block.argtypes = [C.POINTER(Obs), i, i, d, d, vp, pi, pi, pi, pi, vp]
     L.orc_add_ffdotpows.argtypes = [C.POINTER(Obs), vp, vp, i, i, vp, i, i]
+    L.orc_realfft_forward.argtypes = [vp, C.c_long]
+    L.orc_deredden.argtypes = [vp, i]
+    L.orc_rednoise.argtypes = [vp, C.c_long, i, i, d, d]
     L.orc_fill_plane.argtypes = [C.POINTER(Obs)]
     L.orc_num_search_blocks.argtypes = [C.POINTER(Obs)]; L.orc_num_search_blocks.restype = i
     L.orc_num_prepop_blocks.argtypes = [C.POINTER(Obs)]; L.orc_num_prepop_blocks.restype = i
@@ -144,6 +147,25 @@ def init_kernel(z, fftlen):
     hw = C.c_int(0)
     lib().orc_init_kernel(int(z), fftlen, _ptr(out), C.byref(hw))
     return out, hw.value
+
+
+def realfft(series):
+    """Forward real FFT of a float32 series: complex64[n/2] in PRESTO's packed layout."""
+    a = np.ascontiguousarray(series, dtype=np.float32).copy()
+    lib().orc_realfft_forward(_ptr(a), a.size)
+    return a.view(np.complex64)
+
+
+def deredden(fft):
+    a = np.ascontiguousarray(fft, dtype=np.complex64).copy()
+    lib().orc_deredden(_ptr(a), a.size)
+    return a
+
+
+def rednoise(fft, T, startwidth=6, endwidth=100, endfreq=6.0):
+    a = np.ascontiguousarray(fft, dtype=np.complex64).copy()
+    lib().orc_rednoise(_ptr(a), a.size, startwidth, endwidth, float(endfreq), float(T))
+    return a
 
 
 def median(a):

@@ -76,6 +76,10 @@ def load_library():
     L.accelgpu_get_kernel.argtypes = [vp, i, vp]
     L.accelgpu_load_fft.argtypes = [vp, vp, i64]
     L.accelgpu_load_fft_device.argtypes = [vp, vp, i64]
+    L.accelgpu_load_dat.argtypes = [vp, vp, i64, i]
+    L.accelgpu_deredden.argtypes = [vp]
+    L.accelgpu_rednoise.argtypes = [vp, i, i, d, d]
+    L.accelgpu_get_fft.argtypes = [vp, vp, i64]
     L.accelgpu_set_search.argtypes = [vp, pS, i, f]
     L.accelgpu_set_block_range.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     L.accelgpu_fill_plane.argtypes = [vp]
@@ -177,6 +181,24 @@ class AccelSearchGPU:
     def load_fft(self, spectrum):
         a = np.ascontiguousarray(spectrum, dtype=np.complex64)
         _check(self.L.accelgpu_load_fft(self._h, _ptr(a), a.size))
+
+    def load_dat(self, series, deredden=True):
+        """Time series in: realfft (+ deredden) on the device; returns numbins."""
+        a = np.ascontiguousarray(series, dtype=np.float32)
+        _check(self.L.accelgpu_load_dat(self._h, _ptr(a), a.size, int(bool(deredden))))
+        self._numbins = a.size // 2
+        return self._numbins
+
+    def deredden(self):
+        _check(self.L.accelgpu_deredden(self._h))
+
+    def rednoise(self, T, startwidth=6, endwidth=100, endfreq=6.0):
+        _check(self.L.accelgpu_rednoise(self._h, int(startwidth), int(endwidth), float(endfreq), float(T)))
+
+    def get_fft(self, numbins):
+        out = np.empty(int(numbins), dtype=np.complex64)
+        _check(self.L.accelgpu_get_fft(self._h, _ptr(out), out.size))
+        return out
 
     def load_fft_device(self, dev_ptr, numbins, keepalive=None):
         """Use a spectrum already in device memory (e.g. a torch tensor's data_ptr())."""

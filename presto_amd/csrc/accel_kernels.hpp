@@ -226,7 +226,7 @@ __global__ __launch_bounds__(P::NT) void k_block_prep(
         d[a] = x;
         // r*r + i*i with each operation rounded on its own (no fma), so the
         // selected median is bit-identical to a plain C evaluation
-        const float p = __fadd_rn(__fmul_rn(x.x, x.x), __fmul_rn(x.y, x.y));
+        const float p = afft::strict::add(afft::strict::mul(x.x, x.x), afft::strict::mul(x.y, x.y));
         pw[a] = (idx < numdata) ? __float_as_uint(p) : 0xFFFFFFFFu;
     }
 
@@ -244,24 +244,24 @@ __global__ __launch_bounds__(P::NT) void k_block_prep(
 #pragma unroll
         for (int a = 0; a < P::R1; a++) {
             const int idx = P::M1 * a + t;
-            pl[idx] = __fadd_rn(__fmul_rn(d[a].x, d[a].x), __fmul_rn(d[a].y, d[a].y));
+            pl[idx] = afft::strict::add(afft::strict::mul(d[a].x, d[a].x), afft::strict::mul(d[a].y, d[a].y));
         }
         __syncthreads();
         const int n = nice_n, khw = 15;
-        const float scale = __fmul_rn(2.0f / (float) n, (float) ((n / 2) / 20));
+        const float scale = afft::strict::mul(2.0f / (float) n, (float) ((n / 2) / 20));
 #pragma unroll
         for (int a = 0; a < P::R1; a++) {
             const int idx = P::M1 * a + t;
             if (idx < numdata) {
                 const int c = min(max(idx, khw), n - 1 - khw);
                 float acc = 0.0f;
-                for (int k = -15; k <= -6; k++) acc = __fadd_rn(acc, pl[c + k]);
-                for (int k = 6; k <= 15; k++) acc = __fadd_rn(acc, pl[c + k]);
-                const float x = __fmul_rn(acc, scale);
+                for (int k = -15; k <= -6; k++) acc = afft::strict::add(acc, pl[c + k]);
+                for (int k = 6; k <= 15; k++) acc = afft::strict::add(acc, pl[c + k]);
+                const float x = afft::strict::mul(acc, scale);
                 const float y = __int_as_float(0x5f3759df - (__float_as_int(x) >> 1));
-                const float nrm = __fmul_rn(y, __fsub_rn(1.5f, __fmul_rn(__fmul_rn(__fmul_rn(0.5f, x), y), y)));
-                d[a].x = __fmul_rn(d[a].x, nrm);
-                d[a].y = __fmul_rn(d[a].y, nrm);
+                const float nrm = afft::strict::mul(y, afft::strict::sub(1.5f, afft::strict::mul(afft::strict::mul(afft::strict::mul(0.5f, x), y), y)));
+                d[a].x = afft::strict::mul(d[a].x, nrm);
+                d[a].y = afft::strict::mul(d[a].y, nrm);
             }
         }
         __syncthreads(); // the FFT reuses this LDS
@@ -690,10 +690,10 @@ __global__ __launch_bounds__(256) void k_make_rinds(unsigned short *__restrict__
     const int b = blockIdx.y;
     if (j >= USELEN)
         return;
-    const double rr = __dadd_rn(startr[b], __dmul_rn((double) j, 0.5));
-    const double t = __dadd_rn(__dmul_rn(__dmul_rn(2.0, rr), harm_fract), 0.5);
-    const double subr = __dmul_rn((double) (int) t, 0.5);
-    const double q = __dadd_rn(__dmul_rn(__dadd_rn(subr, -(double) sub_rlo[b]), 2.0), 1e-14);
+    const double rr = afft::strict::add(startr[b], afft::strict::mul((double) j, 0.5));
+    const double t = afft::strict::add(afft::strict::mul(afft::strict::mul(2.0, rr), harm_fract), 0.5);
+    const double subr = afft::strict::mul((double) (int) t, 0.5);
+    const double q = afft::strict::add(afft::strict::mul(afft::strict::add(subr, -(double) sub_rlo[b]), 2.0), 1e-14);
     rinds[(size_t) b * USELEN + j] = (unsigned short) (int) q;
 }
 

@@ -35,6 +35,45 @@ template <int DIR> __device__ __forceinline__ c32 mul_i(c32 a)
     return DIR > 0 ? c32{-a.y, a.x} : c32{a.y, -a.x};
 }
 
+// Single operations that are never contracted into a fused multiply-add, for
+// code whose results must equal a plain C evaluation bit for bit.  (The
+// __fmul_rn/__fadd_rn intrinsics are plain operators here and do get fused.)
+namespace strict {
+__device__ __forceinline__ float mul(float a, float b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float add(float a, float b)
+{
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float sub(float a, float b)
+{
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ double mul(double a, double b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ double add(double a, double b)
+{
+#pragma clang fp contract(off)
+    return a + b;
+}
+// x*x + y*y, each operation rounded on its own
+__device__ __forceinline__ float norm2(float x, float y)
+{
+#pragma clang fp contract(off)
+    const float a = x * x;
+    const float b = y * y;
+    return a + b;
+}
+} // namespace strict
+
 // 32nd roots of unity, cos and sin of 2*pi*j/32.
 constexpr float kCos32[32] = {
     1.f, 0.980785251f, 0.923879504f, 0.831469595f, 0.707106769f, 0.555570245f, 0.382683426f,

@@ -2,7 +2,12 @@
 // flags of PRESTO's accelsearch (reference clig/accelsearch_cmd.cli:13-47):
 //
 //   accelsearch_hip [-zmax Z] [-numharm H] [-sigma S] [-flo F] [-fhi F] [-lobin B]
-//                   [-photon] [-locpow] [-median] [-inmem] [-standard] [-device D] file.fft
+//                   [-photon] [-locpow] [-median] [-inmem] [-standard] [-device D]
+//                   file.fft | file.dat | file.sdat
+//
+// A time series (.dat floats, .sdat shorts) is transformed and de-reddened on the
+// GPU first, as the reference does on the host (src/accel_utils.c:1429-1484); no
+// work file is written for it (src/accel_utils.c:1290).
 //
 // Reads file.fft + file.inf, runs the Fourier-domain acceleration search on the
 // GPU and writes the working candidates file <root>_ACCEL_<zmax>.txtcand with the
@@ -87,15 +92,22 @@ int main(int argc, char **argv)
             return 1;
         } else infile = a;
     }
-    if (infile.size() < 5 || infile.substr(infile.size() - 4) != ".fft") {
-        printf("\nInput file ('%s') must be an '.fft' file!\n\n", infile.c_str());
+    auto ends_with = [&](const char *suf) {
+        const size_t n = strlen(suf);
+        return infile.size() > n && infile.compare(infile.size() - n, n, suf) == 0;
+    };
+    const bool is_sdat = ends_with(".sdat"), is_dat = !is_sdat && ends_with(".dat");
+    const bool dat_input = is_dat || is_sdat;
+    if (!dat_input && !ends_with(".fft")) {
+        // src/accel_utils.c:1397-1422
+        printf("\nInput file ('%s') must be an '.fft' or '.[s]dat' file!\n\n", infile.c_str());
         return 1;
     }
     if (zmax < 0 || zmax > 1200 || sigma < 1.0 || sigma > 30.0) {
         printf("\n-zmax must be in 0..1200 and -sigma in 1..30\n\n");
         return 1;
     }
-    const std::string root = infile.substr(0, infile.size() - 4);
+    const std::string root = infile.substr(0, infile.size() - (is_sdat ? 5 : 4));
     double Nd = 0, dt = 0;
     if (!inf_value(root + ".inf", "Number of bins in the time series", &Nd) ||
         !inf_value(root + ".inf", "Width of each time series bin", &dt)) {
@@ -108,12 +120,36 @@ int main(int argc, char **argv)
         return 1;
     }
     fseek(f, 0, SEEK_END);
-    const long long numbins = ftell(f) / 8;
+    const long long filebytes = ftell(f);
     fseek(f, 0, SEEK_SET);
-    std::vector<float> fft((size_t) numbins * 2);
-    if (fread(fft.data(), 8, (size_t) numbins, f) != (size_t) numbins) {
-        printf("\nShort read on '%s'\n\n", infile.c_str());
-        return 1;
+    long long numbins = filebytes / 8;
+    std::vector<float> fft;
+    if (dat_input) {
+        const long long nsamp = filebytes / (is_sdat ? 2 : 4);
+        if (nsamp > 67108864) {
+            printf("\nThe input time series is too large.  Use 'realfft' first.\n\n");
+            return 0;
+        }
+        fft.resize((size_t) nsamp);
+        if (is_sdat) {
+            std::vector<short> tmp((size_t) nsamp);
+            if (fread(tmp.data(), 2, (size_t) nsamp, f) != (size_t) nsamp) {
+                printf("\nShort read on '%s'\n\n", infile.c_str());
+                return 1;
+            }
+            for (long long i = 0; i < nsamp; i++)
+                fft[(size_t) i] = (float) tmp[(size_t) i];
+        } else if (fread(fft.data(), 4, (size_t) nsamp, f) != (size_t) nsamp) {
+            printf("\nShort read on '%s'\n\n", infile.c_str());
+            return 1;
+        }
+        numbins = nsamp / 2;
+    } else {
+        fft.resize((size_t) numbins * 2);
+        if (fread(fft.data(), 8, (size_t) numbins, f) != (size_t) numbins) {
+            printf("\nShort read on '%s'\n\n", infile.c_str());
+            return 1;
+        }
     }
     fclose(f);
 
@@ -132,8 +168,21 @@ int main(int argc, char **argv)
     if (accelgpu_build_kernels(gpu, su.zmax)) die("accelgpu_build_kernels");
     printf("  Harmonic  1/1  has %3d kernel(s) from z = %4d to %4d,  FFT length = %d\n\n", su.numz,
            -su.zmax, su.zmax, su.fftlen);
-    if (accelgpu_load_fft(gpu, fft.data(), numbins)) die("accelgpu_load_fft");
-    const float nph = (photon && lobin == 0) ? fft[0] : 0.f;
+    float nph = 0.f;
+    if (dat_input) {
+        printf("Reading and FFTing the time series...");
+        if (accelgpu_load_dat(gpu, fft.data(), (int64_t) fft.size(), 0)) die("accelgpu_load_dat");
+        printf("done.\n");
+        printf("Removing red-noise...");
+        if (accelgpu_deredden(gpu)) die("accelgpu_deredden");
+        printf("done.\n\n");
+        // The reference reads the photon count from bin 0 after de-reddening has
+        // set it to 1 (src/accel_utils.c:1313, 1531-1533): so does this.
+        if (photon) nph = 1.0f;
+    } else {
+        if (accelgpu_load_fft(gpu, fft.data(), numbins)) die("accelgpu_load_fft");
+        if (photon && lobin == 0) nph = fft[0];
+    }
     if (photon)
         printf("Normalizing powers using %.0f photons.\n\n", nph);
     printf("Full f-fdot plane would need %.2f GB: ", su.plane_bytes / 1073741824.0);
@@ -162,20 +211,22 @@ int main(int argc, char **argv)
 
     char work[4096];
     snprintf(work, sizeof(work), "%s_ACCEL_%d.txtcand", root.c_str(), su.zmax);
-    FILE *w = fopen(work, "w");
-    if (!w) {
+    FILE *w = dat_input ? nullptr : fopen(work, "w");
+    if (!w && !dat_input) {
         perror(work);
         return 1;
     }
-    for (int64_t i = 0; i < nhits; i++)
+    for (int64_t i = 0; w && i < nhits; i++)
         if (added[i]) {
             const int nh = 1 << hits[i].stage;
             const double rr = hits[i].rind * 0.5 / nh, zz = (su.zlo + hits[i].zind * 2.0) / nh;
             fprintf(w, "%-7.2f  %-7.4f  %-2d  %-14.4f  %-14.9f  %-10.4f\n", hits[i].power, sig[i], nh, rr,
                     rr / su.T, zz);
         }
-    fclose(w);
-    printf("  Working candidates in a test format are in '%s'.\n\n", work);
+    if (w) {
+        fclose(w);
+        printf("  Working candidates in a test format are in '%s'.\n\n", work);
+    }
 
     std::stable_sort(cands.begin(), cands.begin() + ncands, [](const accelgpu_cand &a, const accelgpu_cand &b) {
         if (a.sigma != b.sigma) return a.sigma > b.sigma;

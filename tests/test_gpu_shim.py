@@ -80,8 +80,8 @@ def test_command_line_front_end(tmp_path):
     first = [l for l in out.splitlines() if l.startswith("sigma:")][0]
     assert "r: %-14.4f" % best["r"] in first
     # bad input is refused with the reference's message
-    bad = subprocess.run([exe, root + ".dat"], capture_output=True, text=True)
-    assert bad.returncode == 1 and "must be an '.fft' file" in bad.stdout
+    bad = subprocess.run([exe, root + ".txt"], capture_output=True, text=True)
+    assert bad.returncode == 1 and "must be an '.fft' or '.[s]dat' file" in bad.stdout
 
 
 def test_shim_main_loop_standard_mode(tmp_path):
@@ -126,3 +126,28 @@ def test_command_line_standard_mode(tmp_path):
     hits, cands, sig, added = g.search_standard()
     g.close()
     assert len(lines) == int(added.sum()) > 0
+
+
+def test_command_line_dat_input(tmp_path):
+    """accelsearch_hip on a .dat time series: realfft + deredden on the GPU, same
+    candidates as the library path; no work file for .dat input."""
+    import presto_amd as pa
+    exe = os.path.join(ROOT, "presto_amd", "host", "accelsearch_hip")
+    N, dt, zmax, numharm = 1 << 19, 5e-4, 20, 4
+    x = synth.pulsar_series(N, dt, [dict(f=41.7, z=3.0, amp=0.4, duty=0.05)], seed=11).astype(np.float32)
+    root = str(tmp_path / "series_DM7.00")
+    x.tofile(root + ".dat")
+    open(root + ".inf", "w").write(synth.inf_text(os.path.basename(root), N, dt))
+    out = subprocess.check_output([exe, "-zmax", str(zmax), "-numharm", str(numharm), root + ".dat"],
+                                  timeout=170).decode()
+    assert "Removing red-noise...done." in out
+    assert not os.path.exists(root + "_ACCEL_20.txtcand")
+    g = pa.AccelSearchGPU(0)
+    g.configure(N // 2, N, dt, zmax, numharm)
+    g.load_dat(x, deredden=True)
+    hits, cands, sig, added = g.search()
+    g.close()
+    best = cands[np.argmax(cands["sigma"])]
+    first = [l for l in out.splitlines() if l.startswith("sigma:")][0]
+    assert "r: %-14.4f" % best["r"] in first and "harm: %-2d" % best["numharm"] in first
+    assert abs(best["r"] / (N * dt) - 41.7) < 0.01 * 4

@@ -186,3 +186,37 @@ def test_index_helpers(oracle):
     assert L.orc_calc_required_r(0.5, 1001.5) == 501.0
     assert L.orc_calc_required_r(1.0, 536.0) == 536.0
     assert L.orc_index_from_z(-4.0, -200.0) == 98
+
+
+def test_realfft_against_double_precision_transform(oracle):
+    """orc_realfft_forward (reference src/fastffts.c:198-270): packed layout, sign and scale."""
+    rng = np.random.default_rng(4)
+    for n in (1 << 10, 1 << 15):
+        x = rng.standard_normal(n).astype(np.float32)
+        got = oracle.realfft(x)
+        ref = np.fft.rfft(x.astype(np.float64))
+        assert abs(got[0].real - ref[0].real) < 1e-3 and abs(got[0].imag - ref[-1].real) < 1e-3
+        assert np.abs(got[1:] - ref[1:-1]).max() < 2e-6 * np.abs(ref).max() * np.log2(n)
+
+
+def test_deredden_whitens_and_is_deterministic(oracle):
+    """orc_deredden (reference src/accel_utils.c:1301-1374): bin 0 becomes 1+0j, a red
+    spectrum comes out with median power ln 2 everywhere, and the first three bins
+    carry the plain scale of the first 6-bin block."""
+    rng = np.random.default_rng(5)
+    n = 1 << 16
+    amp = 1.0 + 300.0 / (1.0 + np.arange(n) / 50.0)
+    spec = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * amp).astype(np.complex64)
+    out = oracle.deredden(spec)
+    assert out[0] == 1.0
+    pw = np.abs(out[1:]) ** 2
+    for lo, hi in ((1, 2000), (2000, 20000), (20000, n - 1)):
+        assert abs(np.median(pw[lo:hi]) / np.log(2.0) - 1.0) < 0.08
+    p = (spec.real ** 2 + spec.imag ** 2).astype(np.float32)
+    med = np.sort(p[1:7])[2]
+    x = np.float32(np.float64(med) / np.log(2.0))
+    i = np.array([x]).view(np.int32)[0]
+    y = np.array([np.int32(0x5f3759df) - (i >> 1)], dtype=np.int32).view(np.float32)[0]
+    nrm = np.float32(y * np.float32(np.float32(1.5) - np.float32(np.float32(np.float32(np.float32(0.5) * x) * y) * y)))
+    assert out[1].real == np.float32(spec[1].real * nrm) and out[3].imag == np.float32(spec[3].imag * nrm)
+    assert np.array_equal(out, oracle.deredden(spec))
