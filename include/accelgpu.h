@@ -194,6 +194,33 @@ int accelgpu_replay_candidates(const accelgpu_setup *setup, const accelgpu_hit *
                                int64_t n_hits, accelgpu_cand *cands, int64_t max_cands,
                                int64_t *n_cands, float *sigma_out, int32_t *added);
 
+/* ---- after the search: candidate list trimming and optimisation -------------- */
+#define ACCELGPU_MAXHARM 32
+/* ref: rderivs, include/presto.h:161-169 */
+typedef struct accelgpu_rderivs {
+    double pow, phs, dpow, dphs, d2pow, d2phs, locpow;
+} accelgpu_rderivs;
+/* ref: accelcand after optimize_accelcand(), include/accel.h:73-83 */
+typedef struct accelgpu_optcand {
+    float   power, sigma;        /* summed power from the search; sigma recomputed in double */
+    int32_t numharm, pad;
+    double  r, z;                /* search-time position (not overwritten, as in the reference) */
+    double  pows[ACCELGPU_MAXHARM], hirs[ACCELGPU_MAXHARM], hizs[ACCELGPU_MAXHARM];
+    accelgpu_rderivs derivs[ACCELGPU_MAXHARM];
+} accelgpu_optcand;
+/* Sorts by decreasing sigma (ties: decreasing power; stable) and, if `eliminate`,
+ * drops the less significant of harmonically related candidates.  Host only.
+ * ref: sort_accelcands(), eliminate_harmonics(), src/accel_utils.c:278-298, 383-462. */
+int accelgpu_sort_and_eliminate(accelgpu_cand *cands, int64_t n, int eliminate, int64_t *n_kept);
+/* Optimises every candidate against the current spectrum on the GPU: simplex
+ * maximisation of the interpolated power (harmonic-summed and normalised by
+ * local powers when `polish`, each harmonic on its own otherwise), then local
+ * power, power, phase and derivatives per harmonic.  out[i] belongs to cands[i].
+ * ref: optimize_accelcand(), src/accel_utils.c:465-525; max_rz_arr_harmonics(),
+ * max_rz_arr(), src/maximize_rz.c; amoeba(), src/amoeba.c. */
+int accelgpu_optimize_cands(accelgpu_ctx *ctx, const accelgpu_cand *cands, int64_t n, int polish,
+                            accelgpu_optcand *out);
+
 /* ---- per-block forms (hosts that keep the reference's call sequence) ------ */
 /* Copies a host block (numz*USELEN floats, [z][r]) into the in-HBM plane at
  * column 2*rlo.  ref: fund_to_ffdotplane(), src/accel_utils.c:1076-1090. */

@@ -136,6 +136,29 @@ void orc_deredden(orc_cf32 *fft, int numamps);
 void orc_rednoise(orc_cf32 *fft, long numamps, int startwidth, int endwidth, double endfreq,
                   double Tsec);
 
+/* ---- after the search: candidate optimisation (post_oracle.c) ---------------- */
+#define ORC_MAXHARM 32
+typedef struct {           /* rderivs, include/presto.h:161-169 */
+    double pow, phs, dpow, dphs, d2pow, d2phs, locpow;
+} orc_rderivs;
+typedef struct {           /* accelcand with its optimisation results, include/accel.h:73-83 */
+    float power, sigma;
+    int numharm, pad;
+    double r, z;
+    double pows[ORC_MAXHARM], hirs[ORC_MAXHARM], hizs[ORC_MAXHARM];
+    orc_rderivs derivs[ORC_MAXHARM];
+} orc_optcand;
+int orc_z_resp_halfwidth_high(double z);
+void orc_rz_interp(const orc_cf32 *data, long numdata, double r, double z, int kern_half_width,
+                   orc_cf32 *ans);
+double orc_get_localpower3d(const orc_cf32 *data, long numdata, double r, double z);
+void orc_get_derivs3d(const orc_cf32 *data, long numdata, double r, double z, double localpower,
+                      orc_rderivs *res);
+void orc_max_rz(const orc_cf32 *data, long numdata, int nharm, int r_offset, double rin, double zin,
+                int polish, double *rout, double *zout, orc_rderivs *derivs, double *power);
+void orc_optimize_cand(const orc_obs *obs, int polish, orc_optcand *c);
+int orc_sort_and_eliminate(orc_cand *cands, int n, int eliminate);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,12 @@ class Obs(C.Structure):
                 ("halfwidth", C.c_int), ("kern", C.c_void_p), ("nthreads", C.c_int)]
 
 
+MAXHARM = 32
+RDERIVS_DTYPE = np.dtype([("pow", "f8"), ("phs", "f8"), ("dpow", "f8"), ("dphs", "f8"),
+                          ("d2pow", "f8"), ("d2phs", "f8"), ("locpow", "f8")])
+OPTCAND_DTYPE = np.dtype([("power", "f4"), ("sigma", "f4"), ("numharm", "i4"), ("_pad", "i4"),
+                          ("r", "f8"), ("z", "f8"), ("pows", "f8", MAXHARM), ("hirs", "f8", MAXHARM),
+                          ("hizs", "f8", MAXHARM), ("derivs", RDERIVS_DTYPE, MAXHARM)])
 HIT_DTYPE = np.dtype([("power", "f4"), ("sigma", "f4"), ("numharm", "i4"), ("block", "i4"),
                       ("zind", "i4"), ("added", "i4"), ("rind", "i8"), ("r", "f8"), ("z", "f8")])
 CAND_DTYPE = np.dtype([("power", "f4"), ("sigma", "f4"), ("numharm", "i4"), ("_pad", "i4"),
@@ -104,6 +110,13 @@ def lib():
     L.orc_realfft_forward.argtypes = [vp, C.c_long]
     L.orc_deredden.argtypes = [vp, i]
     L.orc_rednoise.argtypes = [vp, C.c_long, i, i, d, d]
+    L.orc_z_resp_halfwidth_high.argtypes = [d]; L.orc_z_resp_halfwidth_high.restype = i
+    L.orc_rz_interp.argtypes = [vp, C.c_long, d, d, i, vp]
+    L.orc_get_localpower3d.argtypes = [vp, C.c_long, d, d]; L.orc_get_localpower3d.restype = d
+    L.orc_get_derivs3d.argtypes = [vp, C.c_long, d, d, d, vp]
+    L.orc_max_rz.argtypes = [vp, C.c_long, i, i, d, d, i, C.POINTER(d), C.POINTER(d), vp, vp]
+    L.orc_optimize_cand.argtypes = [C.POINTER(Obs), i, vp]
+    L.orc_sort_and_eliminate.argtypes = [vp, i, i]; L.orc_sort_and_eliminate.restype = i
     L.orc_fill_plane.argtypes = [C.POINTER(Obs)]
     L.orc_num_search_blocks.argtypes = [C.POINTER(Obs)]; L.orc_num_search_blocks.restype = i
     L.orc_num_prepop_blocks.argtypes = [C.POINTER(Obs)]; L.orc_num_prepop_blocks.restype = i
@@ -297,6 +310,19 @@ class Search:
         sub = np.ascontiguousarray(sub, dtype=np.float32)
         lib().orc_add_ffdotpows(C.byref(self.obs), _ptr(fund), _ptr(sub), int(sub_zlo), sub.shape[1],
                                 _ptr(rinds), numharm, harmnum)
+
+    def optimize(self, cands, polish=True, eliminate=True):
+        """The steps after the search loop (src/accelsearch.c:225-254): sort by sigma,
+        eliminate harmonics, optimise every survivor.  Returns OPTCAND_DTYPE records."""
+        c = np.ascontiguousarray(cands, dtype=CAND_DTYPE).copy()
+        n = lib().orc_sort_and_eliminate(_ptr(c), c.size, int(bool(eliminate)))
+        out = np.zeros(n, dtype=OPTCAND_DTYPE)
+        for k in ("power", "sigma", "numharm", "r", "z"):
+            out[k] = c[k][:n]
+        for j in range(n):
+            one = out[j:j + 1]
+            lib().orc_optimize_cand(C.byref(self.obs), int(bool(polish)), _ptr(one))
+        return out
 
     def search_plane(self, max_hits=4_000_000, max_cands=200_000):
         """Harmonic sum + threshold + list insertion on the plane as it stands."""

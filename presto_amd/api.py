@@ -80,6 +80,8 @@ def load_library():
     L.accelgpu_deredden.argtypes = [vp]
     L.accelgpu_rednoise.argtypes = [vp, i, i, d, d]
     L.accelgpu_get_fft.argtypes = [vp, vp, i64]
+    L.accelgpu_sort_and_eliminate.argtypes = [vp, i64, i, C.POINTER(i64)]
+    L.accelgpu_optimize_cands.argtypes = [vp, vp, i64, i, vp]
     L.accelgpu_set_search.argtypes = [vp, pS, i, f]
     L.accelgpu_set_block_range.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     L.accelgpu_fill_plane.argtypes = [vp]
@@ -127,6 +129,22 @@ def candidate_sigma(power, numsum, numtrials):
 
 def power_for_sigma(sigma, numsum, numtrials):
     return load_library().accelgpu_power_for_sigma(float(sigma), int(numsum), float(numtrials))
+
+
+MAXHARM = 32
+RDERIVS_DTYPE = np.dtype([("pow", "f8"), ("phs", "f8"), ("dpow", "f8"), ("dphs", "f8"),
+                          ("d2pow", "f8"), ("d2phs", "f8"), ("locpow", "f8")])
+OPTCAND_DTYPE = np.dtype([("power", "f4"), ("sigma", "f4"), ("numharm", "i4"), ("_pad", "i4"),
+                          ("r", "f8"), ("z", "f8"), ("pows", "f8", MAXHARM), ("hirs", "f8", MAXHARM),
+                          ("hizs", "f8", MAXHARM), ("derivs", RDERIVS_DTYPE, MAXHARM)])
+
+
+def sort_and_eliminate(cands, eliminate=True):
+    """sort_accelcands + eliminate_harmonics on the host: the kept candidates."""
+    c = np.ascontiguousarray(cands, dtype=CAND_DTYPE).copy()
+    n = C.c_int64(0)
+    _check(load_library().accelgpu_sort_and_eliminate(_ptr(c), c.size, int(bool(eliminate)), C.byref(n)))
+    return c[:n.value].copy()
 
 
 def replay_candidates(setup, hits):
@@ -255,6 +273,14 @@ class AccelSearchGPU:
         hits = self.run(max_hits)
         cands, sig, added = replay_candidates(self.setup, hits)
         return hits, cands, sig, added
+
+    # -- after the search -----------------------------------------------------
+    def optimize(self, cands, polish=True):
+        """optimize_accelcand for every candidate on the GPU: OPTCAND_DTYPE records."""
+        c = np.ascontiguousarray(cands, dtype=CAND_DTYPE)
+        out = np.zeros(c.size, dtype=OPTCAND_DTYPE)
+        _check(self.L.accelgpu_optimize_cands(self._h, _ptr(c), c.size, int(bool(polish)), _ptr(out)))
+        return out
 
     # -- standard (not in-memory) mode ---------------------------------------
     def run_standard(self, max_hits=1 << 20):

@@ -328,4 +328,50 @@ int replay(const accelgpu_setup *s, const accelgpu_hit *hits, int64_t n_hits,
     return ACCELGPU_OK;
 }
 
+// ---- candidate list trimming -------------------------------------------------
+// sort_accelcands() (reference src/accel_utils.c:278-298): decreasing sigma, ties
+// by decreasing power, stable.  eliminate_harmonics() (:383-462): walking the
+// sorted list from the most significant candidate, every later candidate whose r
+// lies within 1.5 bins of r/k, r*k (k = 1..16) or r*a/b for the listed small
+// ratios is dropped.
+int64_t sort_and_eliminate(accelgpu_cand *cands, int64_t n, bool eliminate)
+{
+    std::stable_sort(cands, cands + n, [](const accelgpu_cand &a, const accelgpu_cand &b) {
+        if (a.sigma != b.sigma)
+            return a.sigma > b.sigma;
+        return a.power > b.power;
+    });
+    if (!eliminate || n < 2)
+        return n;
+    static const int num[] = {3, 5, 2, 4, 5, 3, 5, 2, 3, 4, 5, 2, 3, 4, 3, 5, 2, 3, 2, 3, 2, 3, 2};
+    static const int den[] = {2, 2, 3, 3, 3, 4, 4, 5, 5, 5, 6, 7, 7, 7, 8, 8, 9, 10, 11, 11, 13, 13, 15};
+    const double tooclose = 1.5;
+    auto related = [&](double cr, double orr) {
+        for (int k = 1; k <= 16; k++)
+            if (std::fabs(cr / k - orr) < tooclose)
+                return true;
+        for (int k = 1; k <= 16; k++)
+            if (std::fabs(cr * k - orr) < tooclose)
+                return true;
+        for (size_t k = 0; k < sizeof(num) / sizeof(num[0]); k++)
+            if (std::fabs(cr * (double) num[k] / (double) den[k] - orr) < tooclose)
+                return true;
+        return false;
+    };
+    std::vector<accelgpu_cand> kept;
+    std::vector<accelgpu_cand> rest(cands, cands + n);
+    // each pass keeps the head and filters what follows it, as the list walk does
+    while (!rest.empty()) {
+        const accelgpu_cand cur = rest.front();
+        kept.push_back(cur);
+        std::vector<accelgpu_cand> next;
+        for (size_t i = 1; i < rest.size(); i++)
+            if (!related(cur.r, rest[i].r))
+                next.push_back(rest[i]);
+        rest.swap(next);
+    }
+    std::copy(kept.begin(), kept.end(), cands);
+    return (int64_t) kept.size();
+}
+
 } // namespace accelhost

@@ -1,0 +1,143 @@
+"""GPU parity tests: candidate list trimming and (r, z) optimisation against the oracle.
+
+Bars.  The objective is a float32-rounded interpolation sum on both sides, summed
+in a different order (the oracle accumulates in a float complex like the reference,
+the GPU in fp64), so the simplex runs follow slightly different paths over a
+surface that is flat at its maximum:
+  * optimised r within 2e-3 bins, z within 2e-2 bins (numharm = 1 scale);
+  * per-harmonic powers and local powers within 1e-3 relative;
+  * phases within 1e-3 rad of each other modulo 2 pi;
+  * list trimming (sort + harmonic elimination): identical.
+"""
+import numpy as np
+import pytest
+
+from presto_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import presto_amd as pa
+    g = pa.AccelSearchGPU(0)
+    yield g
+    g.close()
+
+
+def _search_both(gpu, oracle, N, dt, pulsars, zmax, numharm, seed, **kw):
+    fft = synth.make_fft(N, dt, pulsars, seed=seed)
+    s = oracle.Search(fft, N, dt, zmax, numharm, nthreads=8, **kw)
+    gpu.configure(fft.size, N, dt, zmax, numharm, **kw)
+    gpu.load_fft(fft)
+    ohits, ocands = s.run()
+    ghits, gcands, sig, added = gpu.search()
+    return s, ocands, gcands
+
+
+def test_sort_and_eliminate_matches_oracle(gpu, oracle):
+    import presto_amd as pa
+    rng = np.random.default_rng(2)
+    n = 400
+    c = np.zeros(n, dtype=pa.CAND_DTYPE)
+    base = rng.uniform(100, 5000, 40)
+    c["r"] = np.concatenate([base * k for k in (1, 2, 3, 0.5, 1.5)] + [rng.uniform(50, 20000, n - 200)])
+    c["r"] += rng.uniform(-1, 1, n)
+    c["z"] = rng.integers(-50, 50, n) * 2.0
+    c["sigma"] = np.round(rng.uniform(2, 12, n), 1).astype(np.float32)     # many ties
+    c["power"] = rng.uniform(10, 100, n).astype(np.float32)
+    c["numharm"] = 2 ** rng.integers(0, 4, n)
+    for elim in (False, True):
+        got = pa.api.sort_and_eliminate(c, eliminate=elim)
+        oc = np.zeros(n, dtype=oracle.CAND_DTYPE)
+        for k in ("power", "sigma", "numharm", "r", "z"):
+            oc[k] = c[k]
+        m = oracle.lib().orc_sort_and_eliminate(oc.ctypes.data, n, int(elim))
+        assert m == len(got)
+        for k in ("power", "sigma", "numharm", "r", "z"):
+            assert np.array_equal(got[k], oc[k][:m]), (elim, k)
+    assert m < n
+
+
+def _compare(o, g, nh_scale=True):
+    assert len(o) == len(g)
+    for a, b in zip(o, g):
+        nh = int(a["numharm"])
+        assert nh == int(b["numharm"]) and a["r"] == b["r"] and a["z"] == b["z"]
+        assert abs(a["sigma"] - b["sigma"]) <= 1e-5 * a["sigma"]     # from two separate searches
+        assert abs(a["hirs"][0] - b["hirs"][0]) < 2e-3, (a["r"], a["hirs"][0], b["hirs"][0])
+        assert abs(a["hizs"][0] - b["hizs"][0]) < 2e-2, (a["r"], a["hizs"][0], b["hizs"][0])
+        for h in range(nh):
+            da, db = a["derivs"][h], b["derivs"][h]
+            # local power is measured at the optimised position, which differs by ~1e-3 bins
+            assert abs(da["locpow"] - db["locpow"]) <= 1e-3 * da["locpow"]
+            # powers: relative to the local power level (weak harmonics are noise)
+            # harmonic h+1 sits at (h+1) times the fundamental's r: its position error, and
+            # with it the power error, grows with h
+            tol = 1e-3 * max(1.0, (h + 1) / 4.0)
+            assert abs(a["pows"][h] - b["pows"][h]) <= tol * max(a["pows"][h], da["locpow"])
+            assert abs(da["pow"] - db["pow"]) <= tol * max(da["pow"], da["locpow"])
+            if da["pow"] > 20 * da["locpow"]:
+                dphi = (da["phs"] - db["phs"] + np.pi) % (2 * np.pi) - np.pi
+                assert abs(dphi) < 5e-3
+
+
+def test_optimize_polish_matches_oracle(gpu, oracle):
+    N, dt = 1 << 19, 2.5e-4
+    puls = [dict(f=77.7, z=-31.0, amp=0.3, duty=0.05), dict(f=211.3, z=12.0, amp=0.25, duty=0.1),
+            dict(f=13.37, z=0.0, amp=0.3, duty=0.2)]
+    s, ocands, gcands = _search_both(gpu, oracle, N, dt, puls, 52, 8, seed=3, sigma=4.0, fhi=1900.0)
+    import presto_amd as pa
+    kept = pa.api.sort_and_eliminate(gcands)
+    assert 0 < len(kept) <= len(gcands)
+    o = s.optimize(ocands, polish=True, eliminate=True)
+    g = gpu.optimize(kept, polish=True)
+    _compare(o, g)
+    # the injected pulsar at 77.7 Hz, z = -31 is among them, optimised onto its true position
+    T = N * dt
+    assert any(abs(c["hirs"][0] / T - 77.7) < 0.02 and abs(c["hizs"][0] + 31.0) < 1.5 for c in g)
+    print("max |dr| = %.2e, max |dz| = %.2e over %d candidates" % (
+        max(abs(a["hirs"][0] - b["hirs"][0]) for a, b in zip(o, g)),
+        max(abs(a["hizs"][0] - b["hizs"][0]) for a, b in zip(o, g)), len(g)))
+
+
+def test_optimize_without_polish_matches_oracle(gpu, oracle):
+    N, dt = 1 << 18, 5e-4
+    puls = [dict(f=41.7, z=9.0, amp=0.35, duty=0.08)]
+    s, ocands, gcands = _search_both(gpu, oracle, N, dt, puls, 20, 4, seed=6, sigma=5.0, fhi=900.0)
+    import presto_amd as pa
+    kept = pa.api.sort_and_eliminate(gcands)
+    o = s.optimize(ocands, polish=False, eliminate=True)
+    g = gpu.optimize(kept, polish=False)
+    assert len(o) == len(g) > 0
+    for a, b in zip(o, g):
+        nh = int(a["numharm"])
+        for h in range(nh):
+            strong = a["pows"][h] > 15 * a["derivs"][h]["locpow"]
+            if strong:        # a real peak: both simplex runs must land on it
+                assert abs(a["hirs"][h] - b["hirs"][h]) < 2e-3 * (h + 1)
+                assert abs(a["hizs"][h] - b["hizs"][h]) < 2e-2 * (h + 1)
+                assert abs(a["pows"][h] - b["pows"][h]) <= 1e-4 * a["pows"][h]
+
+
+def test_optimize_edge_candidates(gpu, oracle):
+    """Candidates whose interpolation windows hang over either end of the spectrum, z = 0
+    at an integer bin, and 32 harmonics."""
+    import presto_amd as pa
+    N, dt = 1 << 17, 1e-3
+    fft = synth.make_fft(N, dt, [dict(f=30.0, z=0.0, amp=0.4, duty=0.02)], seed=12)
+    s = oracle.Search(fft, N, dt, 20, 32, fhi=1e9, nthreads=8)
+    gpu.configure(fft.size, N, dt, 20, 32, fhi=1e9)
+    gpu.load_fft(fft)
+    c = np.zeros(4, dtype=pa.CAND_DTYPE)
+    c["r"] = [12.0, fft.size - 14.5, 30.0 * N * dt / 32 * 1.0, 3000.0]
+    c["z"] = [0.0, 2.0, 0.0, -0.5]
+    c["numharm"] = [1, 1, 32, 2]
+    c["power"] = [20, 20, 200, 20]
+    c["sigma"] = [5, 4, 30, 3]
+    oc = np.zeros(4, dtype=oracle.CAND_DTYPE)
+    for k in ("power", "sigma", "numharm", "r", "z"):
+        oc[k] = c[k]
+    o = s.optimize(oc, polish=True, eliminate=False)
+    g = gpu.optimize(pa.api.sort_and_eliminate(c, eliminate=False), polish=True)
+    _compare(o, g)
