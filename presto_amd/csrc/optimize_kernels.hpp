@@ -10,10 +10,10 @@
 // src/characteristics.c:77-190.
 //
 // One workgroup per optimisation problem.  The simplex logic runs redundantly in
-// every thread on identical values; only the objective is parallel: wavefront w
-// evaluates harmonics w+1, w+1+NW, ... and within a wavefront the 64 lanes share
-// the taps of one interpolation sum (each tap is a Fresnel-integral response
-// sample in fp64 times one spectrum bin).
+// every thread on identical values; only the objective is parallel: all threads
+// share the taps of every harmonic's interpolation sum (each tap is a
+// Fresnel-integral response sample in fp64 times one spectrum bin).  Local
+// powers and derivatives are measured one harmonic per wavefront.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -23,6 +23,7 @@
 namespace optk {
 
 using afft::c32;
+typedef double c64 __attribute__((ext_vector_type(2)));
 
 constexpr int kMaxHarm = 32;
 constexpr double kPi = 3.1415926535897932384626433832795;
@@ -45,6 +46,7 @@ struct Rderivs { // layout of rderivs, include/presto.h:161-169
 
 struct Result {
     double rout, zout;
+    int nfunk[2], pad[2]; // objective evaluations spent by the two simplex runs
     double pows[kMaxHarm];
     Rderivs derivs[kMaxHarm];
 };
@@ -68,48 +70,71 @@ __device__ __forceinline__ int halfwidth_high(double z) // z_resp_halfwidth(z, H
     return m;
 }
 
-// Sample ii of gen_z_response(roffset, numbetween = 1, z, numkern), rounded to
-// float like the reference's response array.
-__device__ inline c32 zresp_tap(double roffset, double z, int numkern, int ii)
+// 1/x to ~1e-15 relative: hardware estimate plus two Newton steps (a full IEEE
+// division costs several times as much; response samples are rounded to float).
+__device__ __forceinline__ double fast_rcp(double x)
 {
-    const double absz = fabs(z);
-    double re, im;
-    if (absz < 1e-4) { // gen_r_response
-        const double x = (double) (numkern / 2 - ii) + roffset; // r / pi
-        double s, c;
-        sincospi(x, &s, &c);
-        const double r = kPi * x;
-        const double sinc = (r == 0.0) ? 1.0 : s / r;
-        re = c * sinc;
-        im = s * sinc;
-        if (roffset < 1e-3 && ii == numkern / 2) {
-            const double r2 = roffset * roffset;
-            re = 1 - 6.579736267392905746 * r2;
-            im = roffset * (kPi - 10.335425560099940058 * r2);
-        }
-        return c32{(float) re, (float) im};
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+
+// Fresnel integrals S(x), C(x) (the rational approximations of the reference's
+// src/fresnl.c:175-216) given sin and cos of pi*x^2/2, which the caller has.
+__device__ __forceinline__ void fresnel_with_trig(double xin, double s, double c, double *S,
+                                                  double *C)
+{
+    using namespace accelk::fres;
+    const double x = fabs(xin), x2 = x * x;
+    double ss, cc;
+    if (x2 < 2.5625) {
+        const double t = x2 * x2;
+        const double sdv = accelk::horner1(t, sd), cdv = accelk::horner(t, cd);
+        const double q = fast_rcp(sdv * cdv);
+        ss = x * x2 * accelk::horner(t, sn) * cdv * q;
+        cc = x * accelk::horner(t, cn) * sdv * q;
+    } else if (x > 36974.0) {
+        ss = cc = 0.5;
+    } else {
+        const double t = fast_rcp(kPi * x2);
+        const double u = t * t;
+        const double fdv = accelk::horner1(u, fd), gdv = accelk::horner1(u, gd);
+        const double q = fast_rcp(fdv * gdv);
+        const double f = 1.0 - u * accelk::horner(u, fn) * gdv * q;
+        const double g = t * accelk::horner(u, gn) * fdv * q;
+        const double tx = t * x; // 1 / (pi x)
+        cc = 0.5 + (f * s - g * c) * tx;
+        ss = 0.5 - (f * c + g * s) * tx;
     }
-    double startr = roffset - 0.5 * z;
-    double ipart;
-    const double fr = modf(startr, &ipart);
-    const double startroffset = startr < 0 ? 1.0 + fr : fr;
-    const double signz = z < 0.0 ? -1.0 : 1.0;
-    const double zd = signz * 1.4142135623730950488 / sqrt(absz);
-    const double cons = zd / 2.0;
-    const double pibyz = kPi / z;
-    startr += (double) (numkern / 2);
+    *S = xin < 0.0 ? -ss : ss;
+    *C = xin < 0.0 ? -cc : cc;
+}
+
+// One sample of the response for |z| >= 1e-4 (see TapGen).  Kept out of line: the
+// simplex kernel reaches it from many places and inlining every copy costs more
+// registers than the call does.
+__device__ __attribute__((noinline)) c64 chirp_tap(int ii, int numkern, double z, double signz,
+                                                   double zd, double cons, double inv_absz,
+                                                   double startr, double startroffset, double sA,
+                                                   double cA)
+{
+    double re, im;
     const double r = startr - (double) ii;
     const double yy = r * zd;
     const double zz = yy + z * zd;
-    double s, c, sy, cy, sz, cz;
-    sincos(pibyz * r * r, &s, &c);
-    accelk::fresnel(yy, &sy, &cy);
-    accelk::fresnel(zz, &sz, &cz);
+    double s1, c1, sy, cy, sz, cz;
+    sincospi(r * r * inv_absz, &s1, &c1);
+    const double s2 = s1 * cA + c1 * sA, c2 = c1 * cA - s1 * sA;
+    fresnel_with_trig(yy, s1, c1, &sy, &cy);
+    fresnel_with_trig(zz, s2, c2, &sz, &cz);
     const double tr = signz * (cz - cy);
     const double ti = sy - sz;
-    re = (tr * c - ti * s) * cons;
-    im = -(tr * s + ti * c) * cons;
-    if (startroffset < 1e-3 && absz < 1e-3 && ii == numkern / 2) {
+    const double s = signz * s1; // sin(pi r^2 / z)
+    re = (tr * c1 - ti * s) * cons;
+    im = -(tr * s + ti * c1) * cons;
+    if (startroffset < 1e-3 && fabs(z) < 1e-3 && ii == numkern / 2) {
         const double z2 = z * z, x2 = startroffset * startroffset;
         re = 1.0 - 0.16449340668482264365 * z2;
         im = -0.5235987755982988731 * z;
@@ -118,8 +143,68 @@ __device__ inline c32 zresp_tap(double roffset, double z, int numkern, int ii)
         re += x2 * (-6.579736267392905746 + 0.9277056288952613070 * z2);
         im += x2 * (3.1006276680299820175 * z);
     }
-    return c32{(float) re, (float) im};
+    return c64{re, im};
 }
+
+// gen_z_response(roffset, numbetween = 1, z, numkern), one sample at a time, in
+// fp64.  (The reference rounds its response array and the interpolation sum to
+// float; that makes its objective noisy at the 1e-8 level, below which its
+// simplex cannot converge: harmonic-summed candidates then wander until the
+// 5000-evaluation cap.  Keeping the objective smooth lets the same simplex
+// converge in ~150 evaluations onto the maximum the reference wanders around.)
+// Everything that does
+// not depend on the sample index is computed once.  With r = startr - ii,
+// yy = r*zd, zz = (r + z)*zd and zd^2 = 2/|z|:
+//   pi*yy^2/2 = pi*r^2/|z|                       (also the outer phase, up to sign)
+//   pi*zz^2/2 = pi*r^2/|z| + pi*(2*sgn(z)*startr + |z|)   (mod 2*pi)
+// so one sincospi per sample serves the phase factor and both Fresnel integrals.
+struct TapGen {
+    bool sinc_mode;
+    int numkern;
+    double roffset, z, signz, zd, cons, inv_absz, startr, startroffset, sA, cA;
+
+    __device__ void init(double roffset_, double z_, int numkern_)
+    {
+        roffset = roffset_;
+        z = z_;
+        numkern = numkern_;
+        const double absz = fabs(z);
+        sinc_mode = absz < 1e-4;
+        if (sinc_mode)
+            return;
+        startr = roffset - 0.5 * z;
+        double ipart;
+        const double fr = modf(startr, &ipart);
+        startroffset = startr < 0 ? 1.0 + fr : fr;
+        signz = z < 0.0 ? -1.0 : 1.0;
+        zd = signz * 1.4142135623730950488 / sqrt(absz);
+        cons = zd / 2.0;
+        inv_absz = 1.0 / absz;
+        startr += (double) (numkern / 2);
+        sincospi(2.0 * signz * startr + absz, &sA, &cA);
+    }
+
+    __device__ c64 tap(int ii) const
+    {
+        double re, im;
+        if (sinc_mode) { // gen_r_response
+            const double x = (double) (numkern / 2 - ii) + roffset; // r / pi
+            double s, c;
+            sincospi(x, &s, &c);
+            const double r = kPi * x;
+            const double sinc = (r == 0.0) ? 1.0 : s / r;
+            re = c * sinc;
+            im = s * sinc;
+            if (roffset < 1e-3 && ii == numkern / 2) {
+                const double r2 = roffset * roffset;
+                re = 1 - 6.579736267392905746 * r2;
+                im = roffset * (kPi - 10.335425560099940058 * r2);
+            }
+            return c64{re, im};
+        }
+        return chirp_tap(ii, numkern, z, signz, zd, cons, inv_absz, startr, startroffset, sA, cA);
+    }
+};
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -157,11 +242,13 @@ __device__ inline c32 wave_rz_interp(const c32 *__restrict__ data, int64_t numda
     if (hidata > numdata - 1)
         hiresp = (int) (numkern - hidata + numdata - 1);
     double ar = 0.0, ai = 0.0;
+    TapGen gen;
+    gen.init(frac, z, numkern);
     for (int ii = loresp + lane; ii < hiresp; ii += 64) {
-        const c32 p = zresp_tap(frac, z, numkern, ii);
+        const c64 p = gen.tap(ii);
         const c32 d = data[lodata + (ii - loresp)];
-        ar += (double) d.x * (double) p.x + (double) d.y * (double) p.y;
-        ai += (double) d.y * (double) p.x - (double) p.y * (double) d.x;
+        ar += (double) d.x * p.x + (double) d.y * p.y;
+        ai += (double) d.y * p.x - p.y * (double) d.x;
     }
     ar = wave_sum(ar);
     ai = wave_sum(ai);
@@ -221,32 +308,107 @@ __device__ inline Rderivs wave_derivs(const c32 *__restrict__ data, int64_t numd
     return d;
 }
 
+// One thread's share (taps lane, lane + stride, ...) of the rz_interp() sum; *done
+// is set when the reference returns early (r outside the data, or z ~ 0 at an
+// integer bin) and then the full answer is returned.
+__device__ inline void rz_interp_share(const c32 *__restrict__ data, int64_t numdata, double r,
+                                       double z, int khw, int first, int stride, double *ar,
+                                       double *ai, bool *done)
+{
+    *ar = *ai = 0.0;
+    *done = true;
+    if (r > (double) numdata - 1.0 || r < 0.0)
+        return;
+    double dint;
+    const double frac = modf(r, &dint);
+    const int64_t intfreq = (int64_t) dint;
+    if (fabs(z) < 1e-4) {
+        if (frac < 1e-5) {
+            *ar = data[intfreq].x;
+            *ai = data[intfreq].y;
+            return;
+        }
+        if (1.0 - frac < 1e-5) {
+            *ar = data[intfreq + 1].x;
+            *ai = data[intfreq + 1].y;
+            return;
+        }
+    }
+    *done = false;
+    const int numkern = 2 * khw;
+    int64_t lodata = intfreq - khw;
+    int loresp = 0, hiresp = numkern;
+    if (lodata < 0) {
+        loresp = (int) -lodata;
+        lodata = 0;
+    }
+    const int64_t hidata = intfreq + khw - 1;
+    if (hidata > numdata - 1)
+        hiresp = (int) (numkern - hidata + numdata - 1);
+    double sr = 0.0, si = 0.0;
+    TapGen gen;
+    gen.init(frac, z, numkern);
+    for (int ii = loresp + first; ii < hiresp; ii += stride) {
+        const c64 p = gen.tap(ii);
+        const c32 d = data[lodata + (ii - loresp)];
+        sr += (double) d.x * p.x + (double) d.y * p.y;
+        si += (double) d.y * p.x - p.y * (double) d.x;
+    }
+    *ar = sr;
+    *ai = si;
+}
+
 template <int NT> struct Objective {
     static constexpr int NW = NT / 64;
     const c32 *data;
     int64_t numdata;
     int nharm, r_offset, khw, polish;
-    double *s_part;        // [NW] in LDS
+    double *s_red;         // [kMaxHarm][NW][2] in LDS: per-wave partial sums
+    double *s_pow;         // [kMaxHarm] in LDS
     const float *s_locpow; // [kMaxHarm] in LDS
 
     // -(summed power) at rz = (r, z / ZSCALE); same value in every thread.
+    // nharm <= NW: each harmonic's interpolation sum is shared by NW/nharm
+    // wavefronts; otherwise every wavefront takes nharm/NW harmonics in turn
+    // (nharm and NW are powers of two).  Partial sums meet in LDS in a fixed order.
     __device__ double operator()(double rz0, double rz1) const
     {
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        double tot = 0.0;
-        for (int i = 1 + wave; i <= nharm; i += NW) {
-            const c32 a = wave_rz_interp(data, numdata, ((double) r_offset + rz0) * i - r_offset,
-                                         rz1 * kZScale * i, khw);
-            const double p = cpower(a);
-            tot += polish ? p / (double) s_locpow[i - 1] : p;
+        const int G = nharm <= NW ? NW / nharm : 1;  // wavefronts per harmonic
+        const int per = nharm <= NW ? 1 : nharm / NW; // harmonics per wavefront
+        for (int k = 0; k < per; k++) {
+            const int h = (wave / G) * per + k; // 0-based harmonic
+            const int g = wave % G;
+            const int i = h + 1;
+            double ar, ai;
+            bool done;
+            rz_interp_share(data, numdata, ((double) r_offset + rz0) * i - r_offset,
+                            rz1 * kZScale * i, khw, g * 64 + lane, G * 64, &ar, &ai, &done);
+            if (done) { // every thread holds the whole answer: count it once
+                if (g != 0) ar = ai = 0.0;
+            } else {
+                ar = wave_sum(ar);
+                ai = wave_sum(ai);
+            }
+            if (lane == 0) {
+                s_red[(h * NW + g) * 2] = ar;
+                s_red[(h * NW + g) * 2 + 1] = ai;
+            }
         }
-        if (lane == 0)
-            s_part[wave] = tot;
+        __syncthreads();
+        if ((int) threadIdx.x < nharm) {
+            double re = 0.0, im = 0.0;
+            for (int g = 0; g < G; g++) {
+                re += s_red[(threadIdx.x * NW + g) * 2];
+                im += s_red[(threadIdx.x * NW + g) * 2 + 1];
+            }
+            const double p = re * re + im * im;
+            s_pow[threadIdx.x] = polish ? p / (double) s_locpow[threadIdx.x] : p;
+        }
         __syncthreads();
         double sum = 0.0;
-#pragma unroll
-        for (int w = 0; w < NW; w++)
-            sum += s_part[w];
+        for (int i = 0; i < nharm; i++)
+            sum += s_pow[i];
         __syncthreads();
         return -sum;
     }
@@ -254,7 +416,7 @@ template <int NT> struct Objective {
 
 // amoeba(), src/amoeba.c:18-92, for a two-dimensional simplex.
 template <class F>
-__device__ inline void simplex(double p[3][2], double y[3], double ftol, const F &funk)
+__device__ inline int simplex(double p[3][2], double y[3], double ftol, const F &funk)
 {
     int nfunk = 0;
     double psum[2] = {p[0][0] + p[1][0] + p[2][0], p[0][1] + p[1][1] + p[2][1]};
@@ -296,10 +458,10 @@ __device__ inline void simplex(double p[3][2], double y[3], double ftol, const F
             double t = y[0]; y[0] = y[ilo]; y[ilo] = t;
             t = p[0][0]; p[0][0] = p[ilo][0]; p[ilo][0] = t;
             t = p[0][1]; p[0][1] = p[ilo][1]; p[ilo][1] = t;
-            return;
+            return nfunk;
         }
         if (nfunk >= 5000)
-            return;
+            return nfunk;
         nfunk += 2;
         double ytry = attempt(ihi, -1.0);
         if (ytry <= y[ilo]) {
@@ -330,7 +492,8 @@ __global__ __launch_bounds__(NT) void k_optimize(const c32 *__restrict__ data, i
                                                 Result *__restrict__ results)
 {
     constexpr int NW = NT / 64;
-    __shared__ double s_part[NW];
+    __shared__ double s_red[kMaxHarm * NW * 2];
+    __shared__ double s_pow[kMaxHarm];
     __shared__ float s_locpow[kMaxHarm];
     const Problem pb = problems[blockIdx.x];
     Result *res = results + blockIdx.x;
@@ -348,7 +511,7 @@ __global__ __launch_bounds__(NT) void k_optimize(const c32 *__restrict__ data, i
     __syncthreads();
 
     Objective<NT> obj{data, numdata, nharm, off, halfwidth_low(fabs(zin * nharm) + 4.0), pb.polish,
-                      s_part, s_locpow};
+                      s_red, s_pow, s_locpow};
     const double step = 0.4;
     double x[3][2] = {{rin - step, zin / kZScale - step},
                       {rin - step, zin / kZScale + step},
@@ -356,7 +519,7 @@ __global__ __launch_bounds__(NT) void k_optimize(const c32 *__restrict__ data, i
     double y[3];
     for (int i = 0; i < 3; i++)
         y[i] = obj(x[i][0], x[i][1]);
-    simplex(x, y, 1.0e-7, obj);
+    const int nf1 = simplex(x, y, 1.0e-7, obj);
 
     obj.khw = halfwidth_high(fabs(x[0][1] * nharm) + 4.0);
     x[1][0] = x[0][0] + 0.01;
@@ -365,12 +528,14 @@ __global__ __launch_bounds__(NT) void k_optimize(const c32 *__restrict__ data, i
     x[2][1] = x[0][1] + 0.01;
     for (int i = 0; i < 3; i++)
         y[i] = obj(x[i][0], x[i][1]);
-    simplex(x, y, 1.0e-10, obj);
+    const int nf2 = simplex(x, y, 1.0e-10, obj);
 
     const double rout = x[0][0], zout = x[0][1] * kZScale;
     if (threadIdx.x == 0) {
         res->rout = rout;
         res->zout = zout;
+        res->nfunk[0] = nf1;
+        res->nfunk[1] = nf2;
     }
     if (!pb.polish) {
         if (wave == 0) {
