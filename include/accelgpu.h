@@ -221,6 +221,34 @@ int accelgpu_sort_and_eliminate(accelgpu_cand *cands, int64_t n, int eliminate, 
 int accelgpu_optimize_cands(accelgpu_ctx *ctx, const accelgpu_cand *cands, int64_t n, int polish,
                             accelgpu_optcand *out);
 
+/* ref: fourierprops, include/presto.h:171-189 (88 bytes; the record of .cand files) */
+typedef struct accelgpu_fourierprops {
+    double r;  float rerr;
+    double z;  float zerr;
+    double w;  float werr;
+    float  pow, powerr, sig, rawpow, phs, phserr, cen, cenerr, pur, purerr, locpow;
+} accelgpu_fourierprops;
+/* Signal properties from power, phase and their derivatives.  Host only.
+ * ref: calc_props(), src/characteristics.c:193-256. */
+int accelgpu_calc_props(const accelgpu_rderivs *derivs, double r, double z, double w,
+                        accelgpu_fourierprops *out);
+/* "value(error)" as in journals with 1 or 2 error digits, left-justified, into
+ * out (at most outlen-1 characters).  Host only.
+ * ref: nice_output_1(), nice_output_2(), src/output.c:6-219. */
+int accelgpu_nice_output(int error_digits, double val, double err, char *out, int outlen);
+/* Writes the two result files of a search from the optimised candidates (in the
+ * order given: the caller passes them sorted as accelgpu_sort_and_eliminate()
+ * left them): the ACCEL text table of fundamentals and harmonics with `inf_text`
+ * (the contents of the .inf file, may be NULL) appended, and the .cand file of
+ * fourierprops.  nph > 0 selects the -photon columns.  The pulsar-database notes
+ * of the reference are not produced (as for telescope "None"); the
+ * candidate-against-candidate notes are.  Host only.
+ * ref: src/accelsearch.c:256-286; output_fundamentals(), output_harmonics(),
+ * src/accel_utils.c:565-835. */
+int accelgpu_write_accel_files(const accelgpu_setup *setup, const accelgpu_optcand *cands,
+                               int64_t n, float nph, const char *accel_path,
+                               const char *cand_path, const char *inf_text);
+
 /* ---- per-block forms (hosts that keep the reference's call sequence) ------ */
 /* Copies a host block (numz*USELEN floats, [z][r]) into the in-HBM plane at
  * column 2*rlo.  ref: fund_to_ffdotplane(), src/accel_utils.c:1076-1090. */

@@ -158,6 +158,20 @@ void orc_max_rz(const orc_cf32 *data, long numdata, int nharm, int r_offset, dou
                 int polish, double *rout, double *zout, orc_rderivs *derivs, double *power);
 void orc_optimize_cand(const orc_obs *obs, int polish, orc_optcand *c);
 int orc_sort_and_eliminate(orc_cand *cands, int n, int eliminate);
+typedef struct {           /* fourierprops, include/presto.h:171-189 (88 bytes) */
+    double r; float rerr; double z; float zerr; double w; float werr;
+    float pow, powerr, sig, rawpow, phs, phserr, cen, cenerr, pur, purerr, locpow;
+} orc_fourierprops;
+typedef struct {           /* rzwerrs, include/presto.h:234-247 */
+    double p, pd, pdd, f, fd, fdd;
+    float perr, pderr, pdderr, ferr, fderr, fdderr;
+} orc_rzwerrs;
+int orc_calc_props(const orc_rderivs *data, double r, double z, double w, orc_fourierprops *res);
+void orc_calc_rzwerrs(const orc_fourierprops *props, double T, orc_rzwerrs *res);
+int orc_nice_output_1(char *output, double val, double err, int len);
+int orc_nice_output_2(char *output, double val, double err, int len);
+int orc_write_accel_files(const orc_obs *obs, orc_optcand *cands, int numcands,
+                          const char *accelnm, const char *candnm, const char *inftext);
 
 #ifdef __cplusplus
 }

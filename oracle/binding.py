@@ -117,6 +117,11 @@ def lib():
     L.orc_max_rz.argtypes = [vp, C.c_long, i, i, d, d, i, C.POINTER(d), C.POINTER(d), vp, vp]
     L.orc_optimize_cand.argtypes = [C.POINTER(Obs), i, vp]
     L.orc_sort_and_eliminate.argtypes = [vp, i, i]; L.orc_sort_and_eliminate.restype = i
+    L.orc_nice_output_1.argtypes = [C.c_char_p, d, d, i]; L.orc_nice_output_1.restype = i
+    L.orc_nice_output_2.argtypes = [C.c_char_p, d, d, i]; L.orc_nice_output_2.restype = i
+    L.orc_calc_props.argtypes = [vp, d, d, d, vp]; L.orc_calc_props.restype = i
+    L.orc_write_accel_files.argtypes = [C.POINTER(Obs), vp, i, C.c_char_p, C.c_char_p, C.c_char_p]
+    L.orc_write_accel_files.restype = i
     L.orc_fill_plane.argtypes = [C.POINTER(Obs)]
     L.orc_num_search_blocks.argtypes = [C.POINTER(Obs)]; L.orc_num_search_blocks.restype = i
     L.orc_num_prepop_blocks.argtypes = [C.POINTER(Obs)]; L.orc_num_prepop_blocks.restype = i
@@ -179,6 +184,13 @@ def rednoise(fft, T, startwidth=6, endwidth=100, endfreq=6.0):
     a = np.ascontiguousarray(fft, dtype=np.complex64).copy()
     lib().orc_rednoise(_ptr(a), a.size, startwidth, endwidth, float(endfreq), float(T))
     return a
+
+
+def nice_output(error_digits, val, err):
+    buf = C.create_string_buffer(128)
+    fn = lib().orc_nice_output_1 if error_digits == 1 else lib().orc_nice_output_2
+    rc = fn(buf, float(val), float(err), 0)
+    return None if rc < 0 else buf.value.decode()
 
 
 def median(a):
@@ -323,6 +335,14 @@ class Search:
             one = out[j:j + 1]
             lib().orc_optimize_cand(C.byref(self.obs), int(bool(polish)), _ptr(one))
         return out
+
+    def write_accel_files(self, optcands, accel_path, cand_path, inf_text=None):
+        c = np.ascontiguousarray(optcands, dtype=OPTCAND_DTYPE).copy()
+        rc = lib().orc_write_accel_files(C.byref(self.obs), _ptr(c), c.size, accel_path.encode(),
+                                         cand_path.encode(),
+                                         None if inf_text is None else inf_text.encode())
+        if rc:
+            raise ValueError("orc_write_accel_files failed")
 
     def search_plane(self, max_hits=4_000_000, max_cands=200_000):
         """Harmonic sum + threshold + list insertion on the plane as it stands."""

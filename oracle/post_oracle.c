@@ -383,3 +383,395 @@ int orc_sort_and_eliminate(orc_cand *cands, int n, int eliminate)
     free(dead);
     return m;
 }
+
+/* ------------------------------------------------------------------------
+ * Derived properties and the ACCEL text / .cand files.
+ * ---------------------------------------------------------------------- */
+#define POST_DBLCORRECT 1e-14
+#define POST_SOL 299792458.0
+
+/* calc_props(), src/characteristics.c:193-256.  Returns 0, or -1 where the
+ * reference prints and exits (power or local power out of bounds). */
+int orc_calc_props(const orc_rderivs *data, double r, double z, double w, orc_fourierprops *res)
+{
+    if (fabs(data->pow) < POST_DBLCORRECT || data->locpow < POST_DBLCORRECT)
+        return -1;
+    const double tmppow = data->pow / data->locpow;
+    const double tmpd2pow = data->d2pow / data->locpow;
+    res->pur = sqrt(1.5 * fabs(tmpd2pow) / tmppow) / POST_PI;
+    if (fabs(tmppow) < POST_DBLCORRECT)
+        res->pur = 1.0;
+    res->purerr = 1.0 / (res->pur * sqrt(10.0 * tmppow));
+    res->r = r;
+    res->rerr = 3.0 / (POST_PI * res->pur * sqrt(6.0 * tmppow));
+    res->z = z;
+    res->zerr = 3.0 * sqrt(10.0) / (POST_PI * res->pur * res->pur * sqrt(tmppow));
+    res->w = w;
+    res->werr = 6.0 * sqrt(105.0) / (POST_PI * res->pur * res->pur * res->pur * sqrt(tmppow));
+    res->pow = tmppow;
+    res->powerr = sqrt(2.0 * tmppow);
+    res->sig = sqrt(2.0 * tmppow - log(POST_PI * tmppow));
+    res->rawpow = data->pow;
+    res->phs = data->phs;
+    res->phserr = 1.0 / res->powerr;
+    res->cen = -data->dphs / POST_TWOPI;
+    res->cenerr = 1.0 / sqrt(24.0 * tmppow);
+    res->locpow = data->locpow;
+    return 0;
+}
+
+/* calc_rzwerrs(), src/characteristics.c:351-394 */
+void orc_calc_rzwerrs(const orc_fourierprops *props, double T, orc_rzwerrs *res)
+{
+    const double T2 = T * T, T3 = T2 * T;
+    const double r2 = props->r * props->r, sr2 = props->rerr * props->rerr, r4 = r2 * r2;
+    const double z2 = props->z * props->z, sz2 = props->zerr * props->zerr;
+    const double tmp = props->r * props->w - 3 * z2;
+    res->f = props->r / T;
+    res->ferr = props->rerr / T;
+    res->fd = props->z / T2;
+    res->fderr = props->zerr / T2;
+    res->fdd = props->w / T3;
+    res->fdderr = props->werr / T3;
+    res->p = T / props->r;
+    res->perr = T * props->rerr / r2;
+    res->pd = -props->z / r2;
+    res->pderr = sqrt(4 * z2 * sr2 / (r4 * r2) + sz2 / r4);
+    if (props->w == 0.0)
+        res->pdd = 0.0;
+    else
+        res->pdd = (2 * z2 - props->r * props->w) / (T * r2 * props->r);
+    res->pdderr = sqrt((props->werr * props->werr * r4 + 16 * sz2 * r2 + 4 * tmp * tmp * sr2) /
+                       (r4 * r4 * T2));
+}
+
+static double copysign_of(double a, double b) { return b < 0.0 ? -fabs(a) : fabs(a); }
+
+/* nice_output_1(), src/output.c:6-114: value with a one-digit error in parentheses. */
+int orc_nice_output_1(char *output, double val, double err, int len)
+{
+    int nint, nfrac, totprec, errexp, errval, outexp;
+    double rndval, outmant;
+    char temp[64];
+
+    sprintf(temp, "There is a problem with 'nice_output()'.\n");
+    errexp = (fabs(err) == 0.0) ? 0 : (int) floor(log10(fabs(err)));
+    errval = (int) floor(fabs(err) * pow(10.0, (double) (-errexp)) + POST_DBLCORRECT + 0.5);
+    if (errval == 10) {
+        errval = 1;
+        errexp++;
+    }
+    rndval = pow(10.0, (double) errexp) * floor(val * pow(10.0, (double) (-errexp)) + 0.5);
+    if (fabs(val) == 0.0) {
+        nint = 1;
+    } else {
+        nint = (int) (ceil(log10(fabs(val))));
+        if (nint == 0)
+            nint++;
+    }
+    nfrac = -errexp;
+    totprec = nint + nfrac;
+    outexp = (fabs(rndval) == 0.0) ? 0 : (int) floor(log10(fabs(rndval)));
+    outmant = rndval * pow(10.0, (double) (-outexp));
+    if (fabs(1.0 - outmant) < POST_DBLCORRECT || fabs(-1.0 - outmant) < POST_DBLCORRECT)
+        totprec++;
+    if ((outexp >= 0 && errexp > 0) && outexp > errexp)
+        sprintf(temp, "% .*f(%d)x10^%d", totprec - 1, copysign_of(outmant, rndval), errval, outexp);
+    else if ((outexp >= 0 && errexp > 0) && outexp == errexp)
+        sprintf(temp, "% d(%d)x10^%d", (int) (copysign_of(outmant, rndval)), errval, outexp);
+    else if (outexp < -4 && outexp >= errexp)
+        sprintf(temp, "% .*f(%d)x10^%d", totprec - 1, copysign_of(outmant, rndval), errval, outexp);
+    else if (outexp < errexp && errexp != 0)
+        sprintf(temp, "% d(%d)x10^%d", (int) (copysign_of(outmant, rndval) + POST_DBLCORRECT),
+                errval, errexp);
+    else if (nfrac == 0 && fabs(rndval) < 1.0e-15)
+        sprintf(temp, "% d(%d)", (int) fabs(rndval), errval);
+    else if (fabs(rndval) <= POST_DBLCORRECT && errexp < -5)
+        sprintf(temp, "0.0(%d)x10^%d", errval, errexp + 1);
+    else
+        sprintf(temp, "% .*f(%d)", nfrac, rndval, errval);
+    if (len == 0)
+        sprintf(output, "%s", temp);
+    else
+        sprintf(output, "%*s", len, temp);
+    return (int) strlen(output);
+}
+
+/* nice_output_2(), src/output.c:117-219: two-digit error.  Returns -1 where the
+ * reference prints "undefined condition" and exits. */
+int orc_nice_output_2(char *output, double val, double err, int len)
+{
+    int errexp, errval, outexp, valexp, tmp;
+    double rndval, outmant;
+    char temp[64];
+
+    errexp = (fabs(err) == 0.0) ? 0 : (int) floor(log10(fabs(err)));
+    errval = (int) floor(fabs(err) * pow(10.0, (double) (-errexp + 1)) + POST_DBLCORRECT + 0.5);
+    if (errval == 100) {
+        errval = 10;
+        errexp++;
+    }
+    rndval = pow(10.0, (double) (errexp - 1)) * floor(val * pow(10.0, (double) (-errexp + 1)) + 0.5);
+    outexp = (rndval == 0.0) ? 0 : (int) floor(log10(fabs(rndval)));
+    valexp = (val == 0.0) ? 0 : (int) floor(log10(fabs(val)));
+    outmant = rndval * pow(10.0, (double) (-outexp));
+    if (outexp < -4) {
+        tmp = outexp - errexp + 1;
+        if (tmp < 2) {
+            if (tmp == 0)
+                sprintf(temp, "% .1f(%d.%d)x10^%d", outmant / 10, errval / 10, errval % 10, outexp + 1);
+            else
+                sprintf(temp, "% .1f(%d.%d)x10^%d", outmant, errval / 10, errval % 10, outexp);
+        } else
+            sprintf(temp, "% .*f(%.2d)x10^%d", tmp, outmant, errval, outexp);
+    } else if (errexp - valexp > 1 && (errexp != 0 && errexp != 1)) {
+        sprintf(temp, "0.0(%d.%d)x10^%d", errval / 10, errval % 10, errexp);
+    } else if (errexp == 0) {
+        if (fabs(rndval) < 0.1)
+            rndval = fabs(rndval);
+        sprintf(temp, "% .1f(%d.%d)", rndval, errval / 10, errval % 10);
+    } else if (errexp < 0) {
+        if (fabs(rndval) * pow(10.0, (double) (-errexp + 1)) < 0.1)
+            rndval = fabs(rndval);
+        if (fabs(rndval) <= POST_DBLCORRECT && errexp < -4)
+            sprintf(temp, "0.0(%d.%d)x10^%d", errval / 10, errval % 10, errexp);
+        else
+            sprintf(temp, "% .*f(%.2d)", -errexp + 1, rndval, errval);
+    } else if (errexp - outexp == 0) {
+        if (errexp == 1)
+            sprintf(temp, "% d(%.2d)", (int) rndval, errval);
+        else
+            sprintf(temp, "% .1f(%d.%d)x10^%d", outmant, errval / 10, errval % 10, errexp);
+    } else if (errexp - outexp == 1) {
+        if (fabs(outmant) < 0.99999999999999)
+            outmant = fabs(outmant);
+        sprintf(temp, "% .1f(%d.%d)x10^%d", outmant / 10.0, errval / 10, errval % 10, errexp);
+    } else if ((errexp > 1 && outexp > 1) && errexp - outexp <= -1) {
+        sprintf(temp, "% .*f(%.2d)x10^%d", outexp - errexp + 1, outmant, errval, outexp);
+    } else if (errexp == 1 && outexp > 0) {
+        sprintf(temp, "% d(%.2d)", (int) rndval, errval);
+    } else {
+        return -1;
+    }
+    if (len == 0)
+        sprintf(output, "%s", temp);
+    else
+        sprintf(output, "%*s", len, temp);
+    return (int) strlen(output);
+}
+
+static void center_string(char *out, const char *in, int width) /* src/accel_utils.c:526-544 */
+{
+    const int len = (int) strlen(in);
+    memset(out, ' ', (size_t) width);
+    out[width] = '\0';
+    if (len >= width)
+        strncpy(out, in, (size_t) width);
+    else
+        memcpy(out + (width - len) / 2, in, (size_t) len);
+}
+
+static void write_val_with_err(FILE *f, double val, double err, int numerr, int width)
+{                               /* :547-562 */
+    char tmpstr[64], ctrstr[64];
+    if (numerr == 1)
+        orc_nice_output_1(tmpstr, val, err, 0);
+    else
+        orc_nice_output_2(tmpstr, val, err, 0);
+    center_string(ctrstr, tmpstr, width);
+    fprintf(f, "%s  ", ctrstr);
+}
+
+/* compare_rzw_cands(), src/accel_utils.c:87-117 */
+static void compare_rzw_cands(const orc_fourierprops *list, int nlist, char *notes)
+{
+    char tmp[32];
+    for (int ii = 0; ii < nlist; ii++)
+        for (int jj = 0; jj < nlist; jj++) {
+            if (ii == jj)
+                continue;
+            if (fabs(list[ii].r - list[jj].r) < 15.0 && fabs(list[ii].z - list[jj].z) > 1.0 &&
+                list[ii].pow > list[jj].pow) {
+                if (strncmp(notes + jj * 20, "                      ", 20) == 0) {
+                    sprintf(tmp, "SL? of Cand %d", ii + 1);
+                    strncpy(notes + jj * 20, tmp, 20);
+                }
+                continue;
+            }
+            for (int kk = 1; kk < 61; kk++)
+                if ((fabs(list[ii].r - list[jj].r / kk) < list[jj].rerr * 3) &&
+                    (fabs(list[ii].z - list[jj].z / kk) < list[jj].zerr * 2)) {
+                    if (strncmp(notes + jj * 20, "                      ", 20) == 0) {
+                        sprintf(tmp, "H %d of Cand %d", kk, ii + 1);
+                        strncpy(notes + jj * 20, tmp, 20);
+                        break;
+                    }
+                }
+        }
+}
+
+static void header_rows(FILE *f, const char **t1, const char **t2, const int *w, int ncols,
+                        const char *alt3)
+{
+    char ctr[64], dash[64];
+    int ii;
+    for (ii = 0; ii < ncols - 1; ii++) {
+        center_string(ctr, t1[ii], w[ii]);
+        fprintf(f, "%s  ", ctr);
+    }
+    center_string(ctr, t1[ii], w[ii]);
+    fprintf(f, "%s\n", ctr);
+    for (ii = 0; ii < ncols - 1; ii++) {
+        center_string(ctr, (alt3 && ii == 3) ? alt3 : t2[ii], w[ii]);
+        fprintf(f, "%s  ", ctr);
+    }
+    center_string(ctr, t2[ii], w[ii]);
+    fprintf(f, "%s\n", ctr);
+    for (ii = 0; ii < ncols - 1; ii++) {
+        memset(dash, '-', (size_t) w[ii]);
+        dash[w[ii]] = '\0';
+        fprintf(f, "%s--", dash);
+    }
+    memset(dash, '-', (size_t) w[ii]);
+    dash[w[ii]] = '\0';
+    fprintf(f, "%s\n", dash);
+}
+
+/* The tail of accelsearch (src/accelsearch.c:256-286): fundamental properties,
+ * output_fundamentals() and output_harmonics() (src/accel_utils.c:565-835; the
+ * pulsar-database comparison is skipped as for telescope "None"), the .inf text
+ * appended, and the .cand file of fourierprops.  Returns 0 or -1. */
+int orc_write_accel_files(const orc_obs *obs, orc_optcand *cands, int numcands,
+                          const char *accelnm, const char *candnm, const char *inftext)
+{
+    static const char *ft1[] = {"", "", "Summed", "Coherent", "Num", "Period", "Frequency",
+                                "FFT 'r'", "Freq Deriv", "FFT 'z'", "Accel", ""};
+    static const char *ft2[] = {"Cand", "Sigma", "Power", "Power", "Harm", "(ms)", "(Hz)", "(bin)",
+                                "(Hz/s)", "(bins)", "(m/s^2)", "Notes"};
+    static const int fw[12] = {4, 5, 6, 8, 4, 16, 15, 15, 15, 11, 15, 20};
+    static const char *ht1[] = {"", "", "", "Power /", "Raw", "FFT 'r'", "Pred 'r'", "FFT 'z'",
+                                "Pred 'z'", "Phase", "Centroid", "Purity", ""};
+    static const char *ht2[] = {"Cand", "Harm", "Sigma", "Loc Pow", "Power", "(bin)", "(bin)",
+                                "(bins)", "(bins)", "(rad)", "(0-1)", "<p> = 1", "Notes"};
+    static const int hw[13] = {5, 4, 5, 15, 11, 18, 13, 12, 9, 12, 10, 10, 20};
+    char tmpstr[64], ctrstr[64];
+    orc_fourierprops *props = (orc_fourierprops *) calloc((size_t) numcands, sizeof(orc_fourierprops));
+    orc_rzwerrs errs;
+    int ii, jj;
+
+    for (ii = 0; ii < numcands; ii++) {                      /* accelsearch.c:258-270 */
+        if (orc_calc_props(&cands[ii].derivs[0], cands[ii].r, cands[ii].z, 0.0, props + ii)) {
+            free(props);
+            return -1;
+        }
+        props[ii].rerr = (float) (ORC_DR) / cands[ii].numharm;
+        props[ii].zerr = (float) (ORC_DZ) / cands[ii].numharm;
+    }
+    FILE *f = fopen(accelnm, "w");
+    if (!f) {
+        free(props);
+        return -1;
+    }
+    char *notes = (char *) malloc((size_t) numcands * 20 + 1);
+    memset(notes, ' ', (size_t) numcands * 20);
+    compare_rzw_cands(props, numcands, notes);
+    header_rows(f, ft1, ft2, fw, 12, NULL);
+    for (ii = 0; ii < numcands; ii++) {
+        const orc_optcand *cand = &cands[ii];
+        double coherent_r = 0.0, coherent_i = 0.0;
+        orc_calc_rzwerrs(props + ii, obs->T, &errs);
+        const double phs0 = cand->derivs[0].phs;
+        for (jj = 0; jj < cand->numharm; jj++) {
+            const orc_rderivs harm = cand->derivs[jj];
+            const double amp = obs->nph > 0.0 ? sqrt(harm.pow / obs->nph) : sqrt(harm.pow / harm.locpow);
+            const double phscorr = phs0 - fmod((jj + 1.0) * phs0, POST_TWOPI);
+            coherent_r += amp * cos(harm.phs + phscorr);
+            coherent_i += amp * sin(harm.phs + phscorr);
+        }
+        const double coherent_pow = coherent_r * coherent_r + coherent_i * coherent_i;
+        sprintf(tmpstr, "%-4d", ii + 1);
+        center_string(ctrstr, tmpstr, fw[0]);
+        fprintf(f, "%s  ", ctrstr);
+        sprintf(tmpstr, "%.2f", cand->sigma);
+        center_string(ctrstr, tmpstr, fw[1]);
+        fprintf(f, "%s  ", ctrstr);
+        sprintf(tmpstr, "%.2f", cand->power);
+        center_string(ctrstr, tmpstr, fw[2]);
+        fprintf(f, "%s  ", ctrstr);
+        sprintf(tmpstr, "%.2f", coherent_pow);
+        center_string(ctrstr, tmpstr, fw[3]);
+        fprintf(f, "%s  ", ctrstr);
+        sprintf(tmpstr, "%d", cand->numharm);
+        center_string(ctrstr, tmpstr, fw[4]);
+        fprintf(f, "%s  ", ctrstr);
+        write_val_with_err(f, errs.p * 1000.0, errs.perr * 1000.0, 1, fw[5]);
+        write_val_with_err(f, errs.f, errs.ferr, 1, fw[6]);
+        write_val_with_err(f, props[ii].r, props[ii].rerr, 2, fw[7]);
+        write_val_with_err(f, errs.fd, errs.fderr, 1, fw[8]);
+        write_val_with_err(f, props[ii].z, props[ii].zerr, 2, fw[9]);
+        const double accel = props[ii].z * POST_SOL / (obs->T * obs->T * errs.f);
+        const double accelerr = props[ii].zerr * POST_SOL / (obs->T * obs->T * errs.f);
+        write_val_with_err(f, accel, accelerr, 2, fw[10]);
+        fprintf(f, "  %.20s\n", notes + ii * 20);
+    }
+    fprintf(f, "\n\n");
+    free(notes);
+
+    header_rows(f, ht1, ht2, hw, 13, obs->nph > 0.0 ? "NumPhot" : NULL);
+    for (ii = 0; ii < numcands; ii++) {
+        orc_optcand *cand = &cands[ii];
+        for (jj = 0; jj < cand->numharm; jj++) {
+            orc_fourierprops hp;
+            orc_rderivs d = cand->derivs[jj];
+            if (obs->nph > 0.0)
+                d.locpow = obs->nph;
+            if (orc_calc_props(&d, cand->hirs[jj], cand->hizs[jj], 0.0, &hp)) {
+                fclose(f);
+                free(props);
+                return -1;
+            }
+            orc_calc_rzwerrs(&hp, obs->T, &errs);
+            if (jj == 0)
+                sprintf(tmpstr, " %-4d", ii + 1);
+            else
+                sprintf(tmpstr, "     ");
+            center_string(ctrstr, tmpstr, hw[0]);
+            fprintf(f, "%s  ", ctrstr);
+            sprintf(tmpstr, "%-4d", jj + 1);
+            center_string(ctrstr, tmpstr, hw[1]);
+            fprintf(f, "%s  ", ctrstr);
+            sprintf(tmpstr, "%.2f", orc_candidate_sigma(hp.pow, 1, 1));
+            center_string(ctrstr, tmpstr, hw[2]);
+            fprintf(f, "%s  ", ctrstr);
+            write_val_with_err(f, hp.pow, hp.powerr, 2, hw[3]);
+            sprintf(tmpstr, "%.3g", hp.rawpow);
+            center_string(ctrstr, tmpstr, hw[4]);
+            fprintf(f, "%s  ", ctrstr);
+            write_val_with_err(f, hp.r, hp.rerr, 2, hw[5]);
+            sprintf(tmpstr, "%.2f", cand->r * (jj + 1));
+            center_string(ctrstr, tmpstr, hw[6]);
+            fprintf(f, "%s  ", ctrstr);
+            write_val_with_err(f, hp.z, hp.zerr, 2, hw[7]);
+            sprintf(tmpstr, "%.2f", cand->z * (jj + 1));
+            center_string(ctrstr, tmpstr, hw[8]);
+            fprintf(f, "%s  ", ctrstr);
+            write_val_with_err(f, hp.phs, hp.phserr, 2, hw[9]);
+            write_val_with_err(f, hp.cen, hp.cenerr, 2, hw[10]);
+            write_val_with_err(f, hp.pur, hp.purerr, 2, hw[11]);
+            fprintf(f, "  %.20s\n", "                    ");
+        }
+    }
+    fprintf(f, "\n\n");
+    if (inftext)
+        fputs(inftext, f);                                   /* the "cat root.inf >>" of :831-833 */
+    fclose(f);
+    f = fopen(candnm, "wb");                                  /* accelsearch.c:282-286 */
+    if (!f) {
+        free(props);
+        return -1;
+    }
+    fwrite(props, sizeof(orc_fourierprops), (size_t) numcands, f);
+    fclose(f);
+    free(props);
+    return 0;
+}

@@ -80,6 +80,9 @@ def load_library():
     L.accelgpu_deredden.argtypes = [vp]
     L.accelgpu_rednoise.argtypes = [vp, i, i, d, d]
     L.accelgpu_get_fft.argtypes = [vp, vp, i64]
+    L.accelgpu_calc_props.argtypes = [vp, d, d, d, vp]
+    L.accelgpu_nice_output.argtypes = [i, d, d, C.c_char_p, i]
+    L.accelgpu_write_accel_files.argtypes = [pS, vp, i64, f, C.c_char_p, C.c_char_p, C.c_char_p]
     L.accelgpu_sort_and_eliminate.argtypes = [vp, i64, i, C.POINTER(i64)]
     L.accelgpu_optimize_cands.argtypes = [vp, vp, i64, i, vp]
     L.accelgpu_set_search.argtypes = [vp, pS, i, f]
@@ -137,6 +140,35 @@ RDERIVS_DTYPE = np.dtype([("pow", "f8"), ("phs", "f8"), ("dpow", "f8"), ("dphs",
 OPTCAND_DTYPE = np.dtype([("power", "f4"), ("sigma", "f4"), ("numharm", "i4"), ("_pad", "i4"),
                           ("r", "f8"), ("z", "f8"), ("pows", "f8", MAXHARM), ("hirs", "f8", MAXHARM),
                           ("hizs", "f8", MAXHARM), ("derivs", RDERIVS_DTYPE, MAXHARM)])
+
+
+FOURIERPROPS_DTYPE = np.dtype([("r", "f8"), ("rerr", "f4"), ("z", "f8"), ("zerr", "f4"), ("w", "f8"),
+                               ("werr", "f4"), ("pow", "f4"), ("powerr", "f4"), ("sig", "f4"),
+                               ("rawpow", "f4"), ("phs", "f4"), ("phserr", "f4"), ("cen", "f4"),
+                               ("cenerr", "f4"), ("pur", "f4"), ("purerr", "f4"), ("locpow", "f4")],
+                              align=True)
+
+
+def nice_output(error_digits, val, err):
+    """value(error) string with 1 or 2 error digits (nice_output_1 / nice_output_2)."""
+    buf = C.create_string_buffer(80)
+    _check(load_library().accelgpu_nice_output(int(error_digits), float(val), float(err), buf, 80))
+    return buf.value.decode()
+
+
+def calc_props(derivs, r, z, w=0.0):
+    d = np.ascontiguousarray(derivs, dtype=RDERIVS_DTYPE).reshape(1)
+    out = np.zeros(1, dtype=FOURIERPROPS_DTYPE)
+    _check(load_library().accelgpu_calc_props(_ptr(d), float(r), float(z), float(w), _ptr(out)))
+    return out[0]
+
+
+def write_accel_files(setup, optcands, accel_path, cand_path, inf_text=None, nph=0.0):
+    """The ACCEL text file (+ .inf text appended) and the .cand file of fourierprops."""
+    c = np.ascontiguousarray(optcands, dtype=OPTCAND_DTYPE)
+    _check(load_library().accelgpu_write_accel_files(
+        C.byref(setup), _ptr(c), c.size, float(nph), accel_path.encode(), cand_path.encode(),
+        None if inf_text is None else inf_text.encode()))
 
 
 def sort_and_eliminate(cands, eliminate=True):

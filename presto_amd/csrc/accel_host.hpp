@@ -1,6 +1,7 @@
 // accel_host.hpp -- host-side helpers of libaccelgpu (no GPU calls).
 #pragma once
 #include <stdint.h>
+#include <string>
 #include "accelgpu.h"
 
 namespace accelhost {
@@ -23,5 +24,12 @@ int replay(const accelgpu_setup *s, const accelgpu_hit *hits, int64_t n_hits, ac
 // Sort by decreasing sigma, optionally drop harmonically related candidates;
 // returns the number kept (in place, at the front).
 int64_t sort_and_eliminate(accelgpu_cand *cands, int64_t n, bool eliminate);
+
+// value(error) strings, derived signal properties and the result files
+std::string nice_output_1(double val, double err);
+std::string nice_output_2(double val, double err, bool *ok);
+int calc_props(const accelgpu_rderivs &d, double r, double z, double w, accelgpu_fourierprops *out);
+int write_accel_files(const accelgpu_setup *su, const accelgpu_optcand *cands, int64_t n, float nph,
+                      const char *accel_path, const char *cand_path, const char *inf_text);
 
 } // namespace accelhost

@@ -11,9 +11,10 @@
 //
 // Reads file.fft + file.inf, runs the Fourier-domain acceleration search on the
 // GPU and writes the working candidates file <root>_ACCEL_<zmax>.txtcand with the
-// reference's line format (src/accel_utils.c:1291-1294).  The search-time
-// candidate list (before optimisation, which this tool does not do) is printed
-// sorted by decreasing sigma (the ordering of src/accel_utils.c:278-298).
+// reference's line format (src/accel_utils.c:1291-1294), then sorts the
+// candidates, removes harmonically related ones, optimises the rest on the GPU and
+// writes <root>_ACCEL_<zmax> (text) and <root>_ACCEL_<zmax>.cand (fourierprops),
+// the tail of the reference's main() (src/accelsearch.c:225-292).
 // -rlo/-rhi are accepted and ignored, as in the reference (its parser marks
 // -flo/-fhi as always present, src/accelsearch_cmd.c:54-60).
 // Mode selection follows src/accel_utils.c:1652-1670 with HBM in place of
@@ -62,7 +63,7 @@ int main(int argc, char **argv)
     int zmax = 200, numharm = 8, device = 0, norm_type = 0;
     long long lobin = 0;
     double sigma = 2.0, flo = 1.0, fhi = 10000.0;
-    bool photon = false, force_inmem = false, force_standard = false;
+    bool photon = false, force_inmem = false, force_standard = false, polish = true, harmremove = true;
     std::string infile;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -86,7 +87,9 @@ int main(int argc, char **argv)
         else if (a == "-median") norm_type = 0;
         else if (a == "-inmem") force_inmem = true;
         else if (a == "-standard") force_standard = true;
-        else if (a == "-otheropt" || a == "-noharmpolish" || a == "-noharmremove") {}
+        else if (a == "-noharmpolish") polish = false;
+        else if (a == "-noharmremove") harmremove = false;
+        else if (a == "-otheropt") {}
         else if (a[0] == '-') {
             printf("\nUnknown option '%s'\n\n", a.c_str());
             return 1;
@@ -228,12 +231,35 @@ int main(int argc, char **argv)
         printf("  Working candidates in a test format are in '%s'.\n\n", work);
     }
 
-    std::stable_sort(cands.begin(), cands.begin() + ncands, [](const accelgpu_cand &a, const accelgpu_cand &b) {
-        if (a.sigma != b.sigma) return a.sigma > b.sigma;
-        return a.power > b.power;
-    });
-    printf("Found %lld candidates (%lld cells above threshold).  Strongest:\n", (long long) ncands,
-           (long long) nhits);
+    printf("Found %lld candidates (%lld cells above threshold).\n", (long long) ncands, (long long) nhits);
+    if (ncands > 0) {
+        int64_t kept = 0;
+        if (accelgpu_sort_and_eliminate(cands.data(), ncands, su.numharm > 1 && harmremove, &kept))
+            die("accelgpu_sort_and_eliminate");
+        if (kept < ncands)
+            printf("Removed %lld likely harmonically related candidates.\n", (long long) (ncands - kept));
+        ncands = kept;
+        std::vector<accelgpu_optcand> opt((size_t) ncands);
+        if (accelgpu_optimize_cands(gpu, cands.data(), ncands, polish ? 1 : 0, opt.data()))
+            die("accelgpu_optimize_cands");
+        std::string inftext;
+        if (FILE *fi = fopen((root + ".inf").c_str(), "rb")) {
+            char buf[4096];
+            size_t got;
+            while ((got = fread(buf, 1, sizeof(buf), fi)) > 0)
+                inftext.append(buf, got);
+            fclose(fi);
+        }
+        char accelnm[4096], candnm[4096];
+        snprintf(accelnm, sizeof(accelnm), "%s_ACCEL_%d", root.c_str(), su.zmax);
+        snprintf(candnm, sizeof(candnm), "%s_ACCEL_%d.cand", root.c_str(), su.zmax);
+        if (accelgpu_write_accel_files(&su, opt.data(), ncands, nph, accelnm, candnm, inftext.c_str()))
+            die("accelgpu_write_accel_files");
+        printf("Optimized %lld candidates; results in '%s' and '%s'.\n", (long long) ncands, accelnm, candnm);
+    } else {
+        printf("No candidates above sigma = %.2f were found.\n\n", su.sigma);
+    }
+    printf("Strongest:\n");
     for (int64_t i = 0; i < std::min<int64_t>(ncands, 20); i++)
         printf("sigma: %-7.4f  pow: %-7.2f  harm: %-2d  r: %-14.4f  z: %-10.4f\n", cands[i].sigma,
                cands[i].power, cands[i].numharm, cands[i].r, cands[i].z);

@@ -143,3 +143,48 @@ def test_optimize_edge_candidates(gpu, oracle):
     o = s.optimize(oc, polish=True, eliminate=False)
     g = gpu.optimize(pa.api.sort_and_eliminate(c, eliminate=False), polish=True)
     _compare(o, g)
+
+
+def test_command_line_writes_accel_and_cand_files(gpu, oracle, tmp_path):
+    """accelsearch_hip end to end: search, trimming, optimisation and both result files,
+    against the oracle running the same tail on its own search."""
+    import os
+    import re
+    import subprocess
+    import presto_amd.api as api
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root_dir, "presto_amd", "host", "accelsearch_hip")
+    N, dt, zmax, numharm = 1 << 19, 2.5e-4, 52, 8
+    puls = [dict(f=77.7, z=-31.0, amp=0.3, duty=0.05), dict(f=211.3, z=12.0, amp=0.25, duty=0.1)]
+    fft = synth.make_fft(N, dt, puls, seed=3)
+    root = str(tmp_path / "psr_DM42.10")
+    synth.write_fft(root, fft, N, dt)
+    out = subprocess.check_output([exe, "-zmax", str(zmax), "-numharm", str(numharm), "-sigma", "4.0",
+                                   "-fhi", "1900", "-inmem", root + ".fft"], timeout=170).decode()
+    assert "Optimized" in out
+    text = open(root + "_ACCEL_52").read()
+    props = np.fromfile(root + "_ACCEL_52.cand", dtype=api.FOURIERPROPS_DTYPE)
+    funds = [l.split() for l in text.splitlines() if re.match(r"^\d", l)]
+    assert len(funds) == len(props) > 0
+    assert " Number of bins in the time series" in text          # the .inf text is appended
+
+    s = oracle.Search(fft, N, dt, zmax, numharm, sigma=4.0, fhi=1900.0, nthreads=8)
+    ohits, ocands = s.run()
+    o = s.optimize(ocands, polish=True, eliminate=True)
+    s.write_accel_files(o, str(tmp_path / "o_ACCEL_52"), str(tmp_path / "o_ACCEL_52.cand"),
+                        open(root + ".inf").read())
+    otext = open(str(tmp_path / "o_ACCEL_52")).read()
+    ofunds = [l.split() for l in otext.splitlines() if re.match(r"^\d", l)]
+    assert len(ofunds) == len(funds)
+    for a, b in zip(ofunds, funds):
+        # Cand, Sigma, Summed power, numharm, r and z columns agree as printed; the coherent
+        # power depends on the optimised phases and may differ in its last digit
+        assert a[0] == b[0] and a[4] == b[4] and a[7] == b[7] and a[9] == b[9]
+        assert abs(float(a[1]) - float(b[1])) <= 0.011 and abs(float(a[2]) - float(b[2])) <= 0.011
+        assert abs(float(a[3]) - float(b[3])) <= 2e-3 * float(a[3]) + 0.011
+    oprops = np.fromfile(str(tmp_path / "o_ACCEL_52.cand"), dtype=api.FOURIERPROPS_DTYPE)
+    assert np.array_equal(oprops["r"], props["r"]) and np.array_equal(oprops["z"], props["z"])
+    assert np.allclose(oprops["pow"], props["pow"], rtol=2e-3)
+    # the pulsar comes out at its injected frequency
+    T = N * dt
+    assert any(abs(p["r"] / T - 77.7) < 0.02 for p in props)
