@@ -135,6 +135,20 @@ int accelgpu_deredden(accelgpu_ctx *ctx);
  * the real parts.  ref: src/rednoise.c:57-188 (defaults 6, 100, 6.0:
  * clig/rednoise_cmd.cli:13-21). */
 int accelgpu_rednoise(accelgpu_ctx *ctx, int startwidth, int endwidth, double endfreq, double T);
+/* Replaces every bin of the given Fourier-bin ranges (sorted by lobin) by the
+ * local noise amplitude (amp, 0), amp^2 = mean of the median powers of the 200
+ * bins below and at the top of the range, over ln 2; ranges below bin 301 are
+ * left alone, ranges past the top are cut, as the zapbirds program does.
+ * In place on the current, library-owned spectrum.
+ * ref: zapbirds(), src/zapping.c:29-81; the loop of src/zapbirds.c:293-300. */
+int accelgpu_zapbirds(accelgpu_ctx *ctx, const double *lobins, const double *hibins, int32_t n);
+/* Reads a birdie list (frequency and width in Hz per line, 'B' prefix for
+ * barycentric lines, '#' comments) into sorted bin ranges for an observation of
+ * T seconds at average velocity baryv (in units of c).  *n_birds is the number
+ * in the file; ACCELGPU_ERR_OVERFLOW if it exceeds max_birds.  Host only.
+ * ref: get_birdies(), src/birdzap.c:6-88. */
+int accelgpu_read_birds(const char *zapfile, double T, double baryv, double *lobins,
+                        double *hibins, int32_t max_birds, int32_t *n_birds);
 /* Copies the current spectrum (numbins complex floats) to the host. */
 int accelgpu_get_fft(accelgpu_ctx *ctx, float *out_complex, int64_t numbins);
 

@@ -1360,3 +1360,46 @@ void orc_rednoise(orc_cf32 *fft, long numamps, int startwidth, int endwidth, dou
     free(out);
     free(powbuf);
 }
+
+/* zapbirds(), src/zapping.c:29-81, applied to an in-memory spectrum the way the
+ * zapbirds program applies it to the file (src/zapbirds.c:293-300): birds in
+ * order of increasing lobin, each one seeing what the earlier ones wrote.  The
+ * two 200-bin median windows start at (int)(lobin - 200) - 100 and (int)hibin - 100
+ * (get_rawbins(), :19-27); bins outside the spectrum read as zero. */
+#define ORC_MEDIANBINS 200
+static float zap_window_median(const orc_cf32 *fft, long numbins, long start)
+{
+    float pw[ORC_MEDIANBINS];
+    for (int ii = 0; ii < ORC_MEDIANBINS; ii++) {
+        const long b = start + ii;
+        pw[ii] = (b >= 0 && b < numbins) ? fft[b].r * fft[b].r + fft[b].i * fft[b].i : 0.0f;
+    }
+    return orc_median(pw, ORC_MEDIANBINS);
+}
+
+void orc_zapbirds(orc_cf32 *fft, long numbins, const double *lobins, const double *hibins, int n)
+{
+    const double top = (double) numbins;                     /* idata.N / 2 */
+    for (int k = 0; k < n; k++) {
+        const double lobin = lobins[k];
+        double hibin = hibins[k];
+        if (lobin >= top - 1)
+            break;
+        if (hibin >= top)
+            hibin = top - 1;
+        const int ilobin = (int) floor(lobin), ihibin = (int) ceil(hibin);
+        const int binstozap = ihibin - ilobin;
+        if (!(lobin - 1.5 * ORC_MEDIANBINS > 1))
+            continue;
+        const float median_lo = zap_window_median(fft, numbins, (long) (int) (lobin - ORC_MEDIANBINS) - ORC_MEDIANBINS / 2);
+        const float median_hi = zap_window_median(fft, numbins, (long) (int) hibin - ORC_MEDIANBINS / 2);
+        const float avgamp = sqrt(0.5 * (median_lo + median_hi) / -log(0.5));
+        for (int ii = 0; ii < binstozap; ii++) {
+            const long b = (long) ilobin + ii;
+            if (b < numbins) {
+                fft[b].r = avgamp;
+                fft[b].i = 0.0f;
+            }
+        }
+    }
+}

@@ -133,6 +133,7 @@ int orc_run_standard(orc_obs *obs, orc_hit *hits, long long max_hits, long long 
 /* In-place forward real FFT into PRESTO's packed layout (bin 0 = DC, Nyquist). */
 void orc_realfft_forward(float *idata, long n);
 void orc_deredden(orc_cf32 *fft, int numamps);
+void orc_zapbirds(orc_cf32 *fft, long numbins, const double *lobins, const double *hibins, int n);
 void orc_rednoise(orc_cf32 *fft, long numamps, int startwidth, int endwidth, double endfreq,
                   double Tsec);
 

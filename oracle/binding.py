@@ -109,6 +109,7 @@ def lib():
     L.orc_add_ffdotpows.argtypes = [C.POINTER(Obs), vp, vp, i, i, vp, i, i]
     L.orc_realfft_forward.argtypes = [vp, C.c_long]
     L.orc_deredden.argtypes = [vp, i]
+    L.orc_zapbirds.argtypes = [vp, C.c_long, vp, vp, i]
     L.orc_rednoise.argtypes = [vp, C.c_long, i, i, d, d]
     L.orc_z_resp_halfwidth_high.argtypes = [d]; L.orc_z_resp_halfwidth_high.restype = i
     L.orc_rz_interp.argtypes = [vp, C.c_long, d, d, i, vp]
@@ -177,6 +178,14 @@ def realfft(series):
 def deredden(fft):
     a = np.ascontiguousarray(fft, dtype=np.complex64).copy()
     lib().orc_deredden(_ptr(a), a.size)
+    return a
+
+
+def zapbirds(fft, lobins, hibins):
+    a = np.ascontiguousarray(fft, dtype=np.complex64).copy()
+    lo = np.ascontiguousarray(lobins, dtype=np.float64)
+    hi = np.ascontiguousarray(hibins, dtype=np.float64)
+    lib().orc_zapbirds(_ptr(a), a.size, _ptr(lo), _ptr(hi), lo.size)
     return a
 
 

@@ -80,6 +80,8 @@ def load_library():
     L.accelgpu_deredden.argtypes = [vp]
     L.accelgpu_rednoise.argtypes = [vp, i, i, d, d]
     L.accelgpu_get_fft.argtypes = [vp, vp, i64]
+    L.accelgpu_zapbirds.argtypes = [vp, vp, vp, C.c_int32]
+    L.accelgpu_read_birds.argtypes = [C.c_char_p, d, d, vp, vp, C.c_int32, C.POINTER(C.c_int32)]
     L.accelgpu_calc_props.argtypes = [vp, d, d, d, vp]
     L.accelgpu_nice_output.argtypes = [i, d, d, C.c_char_p, i]
     L.accelgpu_write_accel_files.argtypes = [pS, vp, i64, f, C.c_char_p, C.c_char_p, C.c_char_p]
@@ -171,6 +173,15 @@ def write_accel_files(setup, optcands, accel_path, cand_path, inf_text=None, nph
         None if inf_text is None else inf_text.encode()))
 
 
+def read_birds(path, T, baryv=0.0, max_birds=4096):
+    """Birdie file -> (lobins, hibins) in Fourier bins, sorted (get_birdies)."""
+    lo = np.zeros(max_birds); hi = np.zeros(max_birds)
+    n = C.c_int32(0)
+    _check(load_library().accelgpu_read_birds(path.encode(), float(T), float(baryv), _ptr(lo), _ptr(hi),
+                                              max_birds, C.byref(n)))
+    return lo[:n.value].copy(), hi[:n.value].copy()
+
+
 def sort_and_eliminate(cands, eliminate=True):
     """sort_accelcands + eliminate_harmonics on the host: the kept candidates."""
     c = np.ascontiguousarray(cands, dtype=CAND_DTYPE).copy()
@@ -244,6 +255,11 @@ class AccelSearchGPU:
 
     def rednoise(self, T, startwidth=6, endwidth=100, endfreq=6.0):
         _check(self.L.accelgpu_rednoise(self._h, int(startwidth), int(endwidth), float(endfreq), float(T)))
+
+    def zapbirds(self, lobins, hibins):
+        lo = np.ascontiguousarray(lobins, dtype=np.float64)
+        hi = np.ascontiguousarray(hibins, dtype=np.float64)
+        _check(self.L.accelgpu_zapbirds(self._h, _ptr(lo), _ptr(hi), lo.size))
 
     def get_fft(self, numbins):
         out = np.empty(int(numbins), dtype=np.complex64)

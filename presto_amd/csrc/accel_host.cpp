@@ -374,4 +374,56 @@ int64_t sort_and_eliminate(accelgpu_cand *cands, int64_t n, bool eliminate)
     return (int64_t) kept.size();
 }
 
+// get_birdies(), reference src/birdzap.c:6-88: topocentric lines are shifted by
+// (1 + baryv), every range is made at least one bin wide, the list comes back
+// sorted by its low edge.
+int read_birds(const char *path, double T, double baryv, double *lobins, double *hibins,
+               int32_t max_birds, int32_t *n_birds)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) {
+        set_error("cannot open birdie file '%s'", path);
+        return ACCELGPU_ERR_ARG;
+    }
+    std::vector<std::pair<double, double>> birds;
+    char line[256];
+    while (fgets(line, sizeof(line), f)) {
+        if (line[0] == '#')
+            continue;
+        double freq = 0.0, width = 0.0, lo, hi;
+        if (line[0] == 'B') {
+            if (sscanf(line, "B%lf %lf", &freq, &width) != 2)
+                continue;
+            lo = (freq - 0.5 * width) * T;
+            hi = (freq + 0.5 * width) * T;
+        } else {
+            if (sscanf(line, "%lf %lf", &freq, &width) != 2)
+                continue;
+            lo = (freq - 0.5 * width) * T * (1.0 + baryv);
+            hi = (freq + 0.5 * width) * T * (1.0 + baryv);
+        }
+        if (hi - lo < 1.0) {
+            const double mid = 0.5 * (hi + lo);
+            lo = mid - 0.5;
+            hi = mid + 0.5;
+        }
+        birds.emplace_back(lo, hi);
+    }
+    fclose(f);
+    std::stable_sort(birds.begin(), birds.end(),
+                     [](const std::pair<double, double> &a, const std::pair<double, double> &b) {
+                         return a.first < b.first;
+                     });
+    *n_birds = (int32_t) birds.size();
+    if ((int32_t) birds.size() > max_birds) {
+        set_error("%zu birds but room for %d", birds.size(), max_birds);
+        return ACCELGPU_ERR_OVERFLOW;
+    }
+    for (size_t i = 0; i < birds.size(); i++) {
+        lobins[i] = birds[i].first;
+        hibins[i] = birds[i].second;
+    }
+    return ACCELGPU_OK;
+}
+
 } // namespace accelhost

@@ -25,6 +25,11 @@ int replay(const accelgpu_setup *s, const accelgpu_hit *hits, int64_t n_hits, ac
 // returns the number kept (in place, at the front).
 int64_t sort_and_eliminate(accelgpu_cand *cands, int64_t n, bool eliminate);
 
+// Birdie list (frequency and width in Hz per line; 'B' lines are barycentric and
+// not Doppler-shifted; '#' comments) as sorted Fourier-bin ranges.
+int read_birds(const char *path, double T, double baryv, double *lobins, double *hibins,
+               int32_t max_birds, int32_t *n_birds);
+
 // value(error) strings, derived signal properties and the result files
 std::string nice_output_1(double val, double err);
 std::string nice_output_2(double val, double err, bool *ok);

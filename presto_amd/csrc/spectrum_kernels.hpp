@@ -206,4 +206,75 @@ __global__ __launch_bounds__(256) void k_red_apply(c32 *__restrict__ fft,
         fft[0] = c32{1.0f, 0.0f};
 }
 
+// ---------------------------------------------------------------------------
+// zapbirds() (reference src/zapping.c:29-81): every bin of a birdie range is set
+// to (avgamp, 0), avgamp = sqrt(mean of the median powers of the 200 bins below
+// and the 200 bins at the top of the range / ln 2).  Birds are applied in order
+// and a later one sees what earlier ones wrote, so one workgroup walks the list;
+// wavefront 0 and 1 find the two medians, then all threads write the range.
+// ---------------------------------------------------------------------------
+__device__ inline float wave_median200(const c32 *__restrict__ fft, int64_t numbins, int64_t start)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t pw[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int idx = lane + 64 * e;
+        pw[e] = 0xFFFFFFFFu;
+        if (idx < 200) {
+            const int64_t b = start + idx;
+            float p = 0.0f;
+            if (b >= 0 && b < numbins)
+                p = afft::strict::norm2(fft[b].x, fft[b].y);
+            pw[e] = __float_as_uint(p);
+        }
+    }
+    const int k = (200 - 1) / 2;
+    uint32_t prefix = 0;
+    for (int bit = 30; bit >= 0; bit--) {
+        const uint32_t cand = prefix | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            c += __popcll(__ballot(pw[e] < cand));
+        if (c <= k)
+            prefix = cand;
+    }
+    return __uint_as_float(prefix);
+}
+
+__global__ __launch_bounds__(256) void k_zapbirds(c32 *__restrict__ fft, int64_t numbins,
+                                                 const double *__restrict__ lobins,
+                                                 const double *__restrict__ hibins, int n)
+{
+    __shared__ float s_med[2];
+    const int wave = threadIdx.x >> 6;
+    const double top = (double) numbins;
+    for (int k = 0; k < n; k++) {
+        const double lobin = lobins[k];
+        double hibin = hibins[k];
+        if (lobin >= top - 1)
+            break;
+        if (hibin >= top)
+            hibin = top - 1;
+        if (!(lobin - 300.0 > 1))
+            continue;
+        const int ilobin = (int) floor(lobin), ihibin = (int) ceil(hibin);
+        if (wave == 0) {
+            const float m = wave_median200(fft, numbins, (int64_t) (int) (lobin - 200) - 100);
+            if (threadIdx.x == 0) s_med[0] = m;
+        } else if (wave == 1) {
+            const float m = wave_median200(fft, numbins, (int64_t) (int) hibin - 100);
+            if ((threadIdx.x & 63) == 0) s_med[1] = m;
+        }
+        __syncthreads();
+        // float sum of the medians, then double arithmetic, rounded to float
+        const float avgamp = (float) sqrt(0.5 * (double) afft::strict::add(s_med[0], s_med[1]) / 0.69314718055994530942);
+        for (int64_t b = (int64_t) ilobin + threadIdx.x; b < ihibin && b < numbins; b += 256)
+            fft[b] = c32{avgamp, 0.0f};
+        __threadfence_block();
+        __syncthreads(); // the next bird may read what this one wrote
+    }
+}
+
 } // namespace speck

@@ -106,3 +106,20 @@ def test_dat_input_end_to_end(gpu, oracle):
     assert np.abs(po - pg).max() <= 1e-3 * po.max()
     best_o = ocands[np.argmax(ocands["sigma"])]; best_g = gcands[np.argmax(gcands["sigma"])]
     assert (best_o["r"], best_o["z"], best_o["numharm"]) == (best_g["r"], best_g["z"], best_g["numharm"])
+
+
+def test_zapbirds_bit_exact_on_shared_spectrum(gpu, oracle):
+    n = 1 << 18
+    spec = oracle.realfft(_series(1 << 19, 8, red=0.02)).copy()
+    # overlapping and adjacent ranges (a later bird's median window covers an earlier
+    # zap), one too low to be zapped, one hanging over the top, one past it
+    lo = np.array([120.0, 500.25, 760.5, 9000.0, 9150.7, 60000.0, n - 50.5, n + 10.0])
+    hi = np.array([130.0, 520.75, 790.1, 9100.3, 9151.7, 60400.0, n + 20.0, n + 30.0])
+    want = oracle.zapbirds(spec, lo, hi)
+    gpu.load_fft(spec)
+    gpu.zapbirds(lo, hi)
+    got = gpu.get_fft(n)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(got[100:140], spec[100:140])                  # below bin 301: untouched
+    assert got[510].imag == 0.0 and got[510].real > 0 and got[510] == got[505]
+    assert not np.array_equal(got[60000:60400], spec[60000:60400])

@@ -167,3 +167,19 @@ def test_synthetic_inf_text_round_trip(tmp_path):
     assert os.path.getsize(tmp_path / "x.fft") == 1024 * 8
     txt = open(tmp_path / "x.inf").read()
     assert "Number of bins in the time series" in txt and "=  2048" in txt
+
+
+def test_read_birds_follows_the_reference_rules(tmp_path):
+    """get_birdies (reference src/birdzap.c:6-88): comments, barycentric 'B' lines, Doppler
+    factor on the others, minimum width of one bin, sorted by low edge."""
+    import presto_amd.api as api
+    p = tmp_path / "birds.zaplist"
+    p.write_text("# freq width\n60.0 0.1\nB 10.0 0.02\n120.0 0.0001\n# done\n 0.5 0.01\n")
+    T, v = 1000.0, 1e-4
+    lo, hi = api.read_birds(str(p), T, v)
+    assert len(lo) == 4 and np.all(np.diff(lo) > 0)
+    k = 1.0 + v
+    want = sorted([((60.0 - 0.05) * T * k, (60.0 + 0.05) * T * k), ((10.0 - 0.01) * T, (10.0 + 0.01) * T),
+                   (120.0 * T * k - 0.5, 120.0 * T * k + 0.5), ((0.5 - 0.005) * T * k, (0.5 + 0.005) * T * k)])
+    assert np.allclose(lo, [w[0] for w in want], rtol=0, atol=1e-7)
+    assert np.allclose(hi, [w[1] for w in want], rtol=0, atol=1e-7)
