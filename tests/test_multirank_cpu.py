@@ -124,3 +124,54 @@ def test_long_series_hit_merge_world2():
         assert p.exitcode == 0
     want = _fake_hits(37, 5)
     assert np.array_equal(got[0], want) and np.array_equal(got[1], want)
+
+
+def _sift_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from presto_amd import batch, pipeline, sifting
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T = 500.0
+    # four DM trials dealt round-robin; a pulsar at r = 20000 seen at DM 10, 20, 30
+    lists = {}
+    for i, dm in enumerate([0.0, 10.0, 20.0, 30.0]):
+        cands = []
+        if dm > 0:
+            c = sifting.Candidate(1, 12.0 + (dm == 20.0), 4, 60.0, 200.0, 20000.0 + 0.1 * i, 2.0,
+                                  "%.2f" % dm, "b_DM%.2f_ACCEL_50" % dm, T)
+            c.harm_pows = np.array([30.0, 15.0, 10.0, 9.0]); c.harms_to_snr(); c.hits = [(dm, c.snr, c.sigma)]
+            cands.append(c)
+        c = sifting.Candidate(2, 9.0, 2, 30.0, 150.0, 40000.0 + 0.2, 4.0, "%.2f" % dm,
+                              "b_DM%.2f_ACCEL_50" % dm, T)
+        c.harm_pows = np.array([20.0, 12.0]); c.harms_to_snr(); c.hits = [(dm, c.snr, c.sigma)]
+        cands.append(c)
+        lists[i] = sifting.Candlist(cands)
+    mine = batch.shard_trials(4, rank, world)
+    rec = np.concatenate([pipeline.candlist_to_records(lists[i], i) for i in mine])
+    allrec = batch._allgather_generic(rec, None)
+    if rank == 0:
+        names = ["b_DM%.2f_ACCEL_50" % dm for dm in (0.0, 10.0, 20.0, 30.0)]
+        order = np.lexsort((allrec[:, 1], allrec[:, 0]))
+        cl = pipeline.records_to_candlist(allrec[order], names, {i: T for i in range(4)})
+        cl = pipeline.sift(cl, ["0.00", "10.00", "20.00", "30.00"], 2, 2.0, verbosity=0)
+        q.put([(c.DM, round(c.r), len(c.hits), c.sigma) for c in cl])
+    dist.destroy_process_group()
+
+
+def test_sifting_after_gather_world2():
+    """Fundamentals found on two ranks are all-gathered and sifted on rank 0: the pulsar
+    collects its three DM hits; the candidate that peaks at DM 0 is dropped; the 2nd
+    harmonic goes too."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sift_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert out == [(20.0, 20000, 3, 13.0)]
