@@ -27,3 +27,18 @@ np.savez_compressed(os.path.join(ROOT, "tests", "golden", "search_small.npz"),
                     hits=hits, cands=cands, block0_rows=blk[::5, ::37].copy(),
                     kernel_z10=ob.init_kernel(10, s.fftlen)[0][::16].copy())
 print("hits", len(hits), "cands", len(cands), "added", int(hits["added"].sum()))
+
+# ---- the tail and the pre-steps: tests/golden/post_small.npz + post_small_ACCEL_30 -------
+opt = s.optimize(cands, polish=True, eliminate=True)
+inf = synth.inf_text("post_small_DM7.50", N, dt)
+accel = os.path.join(ROOT, "tests", "golden", "post_small_DM7.50_ACCEL_30")
+s.write_accel_files(opt, accel, accel + ".cand", inf)
+rng = np.random.default_rng(11)
+series = (rng.standard_normal(1 << 13) + 0.05 * np.cumsum(rng.standard_normal(1 << 13)) + 5).astype(np.float32)
+spec = ob.realfft(series)
+birds_lo, birds_hi = np.array([700.2, 1500.0]), np.array([712.9, 1501.0])
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "post_small.npz"),
+                    opt=opt, series=series, realfft=spec, deredden=ob.deredden(spec),
+                    rednoise=ob.rednoise(spec, (1 << 13) * 1e-3), birds_lo=birds_lo, birds_hi=birds_hi,
+                    zapped=ob.zapbirds(spec, birds_lo, birds_hi))
+print("optimised", len(opt), "of", len(cands))

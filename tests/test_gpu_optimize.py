@@ -188,3 +188,21 @@ def test_command_line_writes_accel_and_cand_files(gpu, oracle, tmp_path):
     # the pulsar comes out at its injected frequency
     T = N * dt
     assert any(abs(p["r"] / T - 77.7) < 0.02 for p in props)
+
+
+def test_golden_optimised_candidates(gpu):
+    """Committed vectors (tests/golden/search_small.npz + post_small.npz): searching the golden
+    spectrum, trimming and optimising on the GPU lands on the golden optimised candidates."""
+    import os
+    import presto_amd.api as api
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = np.load(os.path.join(here, "golden", "search_small.npz"))
+    p = np.load(os.path.join(here, "golden", "post_small.npz"))
+    N, dt = int(g["N"]), float(g["dt"])
+    gpu.configure(g["fft"].size, N, dt, int(g["zmax"]), int(g["numharm"]), fhi=1e9)
+    gpu.load_fft(g["fft"])
+    hits, cands, sig, added = gpu.search()
+    kept = api.sort_and_eliminate(cands)
+    out = gpu.optimize(kept)
+    gold = p["opt"]
+    _compare(gold, out)

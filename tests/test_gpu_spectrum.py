@@ -123,3 +123,23 @@ def test_zapbirds_bit_exact_on_shared_spectrum(gpu, oracle):
     assert np.array_equal(got[100:140], spec[100:140])                  # below bin 301: untouched
     assert got[510].imag == 0.0 and got[510].real > 0 and got[510] == got[505]
     assert not np.array_equal(got[60000:60400], spec[60000:60400])
+
+
+def test_golden_pre_steps(gpu):
+    """Committed vectors (tests/golden/post_small.npz): the three in-place filters reproduce
+    them bit for bit from the golden spectrum; the device transform of the golden series
+    agrees with the golden spectrum to float round-off."""
+    import os
+    p = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "post_small.npz"))
+    spec = p["realfft"]
+    n = spec.size
+    gpu.load_fft(spec); gpu.deredden()
+    assert np.array_equal(gpu.get_fft(n).view(np.uint32), p["deredden"].view(np.uint32))
+    gpu.load_fft(spec); gpu.rednoise(2 * n * 1e-3)
+    assert np.array_equal(gpu.get_fft(n).view(np.uint32), p["rednoise"].view(np.uint32))
+    gpu.load_fft(spec); gpu.zapbirds(p["birds_lo"], p["birds_hi"])
+    assert np.array_equal(gpu.get_fft(n).view(np.uint32), p["zapped"].view(np.uint32))
+    gpu.load_dat(p["series"], deredden=False)
+    got = gpu.get_fft(n)
+    rms = np.sqrt(np.mean(np.abs(spec[1:]) ** 2))
+    assert np.abs(got[1:] - spec[1:]).max() <= 1e-5 * rms + 2e-7 * abs(spec[0].real)

@@ -183,3 +183,50 @@ def test_read_birds_follows_the_reference_rules(tmp_path):
                    (120.0 * T * k - 0.5, 120.0 * T * k + 0.5), ((0.5 - 0.005) * T * k, (0.5 + 0.005) * T * k)])
     assert np.allclose(lo, [w[0] for w in want], rtol=0, atol=1e-7)
     assert np.allclose(hi, [w[1] for w in want], rtol=0, atol=1e-7)
+
+
+POST = os.path.join(ROOT, "tests", "golden", "post_small.npz")
+
+
+def test_oracle_reproduces_post_golden(oracle, tmp_path):
+    """The committed vectors of the tail and the pre-steps (tests/golden/post_small.npz and
+    the ACCEL text beside it) still come out of the oracle bit for bit."""
+    g = np.load(GOLD)
+    p = np.load(POST)
+    s = oracle.Search(g["fft"], int(g["N"]), float(g["dt"]), int(g["zmax"]), int(g["numharm"]), fhi=1e9)
+    hits, cands = s.run()
+    opt = s.optimize(cands, polish=True, eliminate=True)
+    assert opt.tobytes() == p["opt"].tobytes()
+    name = str(tmp_path / "post_small_DM7.50_ACCEL_30")
+    from presto_amd import synth
+    s.write_accel_files(opt, name, name + ".cand", synth.inf_text("post_small_DM7.50", int(g["N"]), float(g["dt"])))
+    gold = os.path.join(ROOT, "tests", "golden", "post_small_DM7.50_ACCEL_30")
+    assert open(name).read() == open(gold).read()
+    assert open(name + ".cand", "rb").read() == open(gold + ".cand", "rb").read()
+    spec = oracle.realfft(p["series"])
+    assert np.array_equal(spec, p["realfft"])
+    assert np.array_equal(oracle.deredden(spec), p["deredden"])
+    assert np.array_equal(oracle.rednoise(spec, 8192 * 1e-3), p["rednoise"])
+    assert np.array_equal(oracle.zapbirds(spec, p["birds_lo"], p["birds_hi"]), p["zapped"])
+
+
+def test_product_writer_reproduces_golden_accel_file(tmp_path):
+    """The library's writer on the golden optimised candidates gives the golden ACCEL text
+    and .cand bytes; the sifting parser reads it back."""
+    import presto_amd as pa
+    import presto_amd.api as api
+    from presto_amd import sifting, synth
+    g = np.load(GOLD)
+    p = np.load(POST)
+    N, dt = int(g["N"]), float(g["dt"])
+    setup = pa.plan(N // 2, N, dt, int(g["zmax"]), int(g["numharm"]), fhi=1e9)
+    opt = np.zeros(len(p["opt"]), dtype=api.OPTCAND_DTYPE)
+    for k in opt.dtype.names:
+        opt[k] = p["opt"][k]
+    name = str(tmp_path / "post_small_DM7.50_ACCEL_30")
+    api.write_accel_files(setup, opt, name, name + ".cand", synth.inf_text("post_small_DM7.50", N, dt))
+    gold = os.path.join(ROOT, "tests", "golden", "post_small_DM7.50_ACCEL_30")
+    assert open(name).read() == open(gold).read()
+    assert open(name + ".cand", "rb").read() == open(gold + ".cand", "rb").read()
+    cl = sifting.candlist_from_candfile(gold)
+    assert len(cl) == len(opt) and cl[0].DM == 7.5 and cl[0].numharm == opt["numharm"][0]
