@@ -225,6 +225,7 @@ def main():
         print(json.dumps(line))
     g.close()
     if world > 1:
+        dist.barrier()          # rank 0 reports a little longer; leave together
         dist.destroy_process_group()
 
 
