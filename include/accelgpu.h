@@ -121,7 +121,9 @@ int accelgpu_load_fft_device(accelgpu_ctx *ctx, const void *fft_complex_dev, int
 /* Time-series input: uploads n float samples, transforms them on the device into
  * the packed .fft layout (bin 0 = DC, Nyquist) and, if `deredden` is non-zero,
  * removes red noise; the result becomes the current spectrum (numbins = n/2).
- * n/2 must be a power of two (2^9..2^25); n <= 67108864 as in the reference.
+ * n is even, 1024 <= n <= 67108864 (the reference's limit); power-of-two lengths go
+ * through the LDS transforms directly, other lengths through a chirp-z
+ * convolution on top of them.
  * ref: the .dat branch of create_accelobs(), src/accel_utils.c:1429-1484;
  * realfft(), src/fastffts.c:198-270; deredden(), src/accel_utils.c:1301-1374. */
 int accelgpu_load_dat(accelgpu_ctx *ctx, const float *series, int64_t n, int deredden);

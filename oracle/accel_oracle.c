@@ -374,7 +374,7 @@ static inline orc_cf32 cmulf(orc_cf32 a, orc_cf32 b)
     return c;
 }
 
-void orc_fft(orc_cf32 *data, long n, int isign)
+static void fft_pow2(orc_cf32 *data, long n, int isign)
 {
     if (n <= 1)
         return;
@@ -520,6 +520,85 @@ void orc_init_kernel(int z, int fftlen, orc_cf32 *out, int *halfwidth) /* src/ac
     orc_fft(out, fftlen, -1);
     if (halfwidth)
         *halfwidth = hw;
+}
+
+/* Lengths that are not powers of two (time series of any even length): the
+ * reference hands them to FFTW, whose results are the exact transform up to
+ * float round-off.  Here: the chirp-z identity in double precision on top of a
+ * radix-2 double FFT, rounded to float at the end. */
+static void dfft_pow2(double *re, double *im, long n, int isign)
+{
+    for (long i = 1, j = 0; i < n; i++) {                     /* bit reversal */
+        long bit = n >> 1;
+        for (; j & bit; bit >>= 1)
+            j ^= bit;
+        j ^= bit;
+        if (i < j) {
+            double t = re[i]; re[i] = re[j]; re[j] = t;
+            t = im[i]; im[i] = im[j]; im[j] = t;
+        }
+    }
+    for (long len = 2; len <= n; len <<= 1) {
+        const long half = len >> 1;
+        for (long k = 0; k < half; k++) {
+            const double a = isign * 2.0 * ORC_PI * (double) k / (double) len;
+            const double wr = cos(a), wi = sin(a);
+            for (long i = k; i < n; i += len) {
+                const long j = i + half;
+                const double tr = re[j] * wr - im[j] * wi, ti = re[j] * wi + im[j] * wr;
+                re[j] = re[i] - tr; im[j] = im[i] - ti;
+                re[i] += tr;        im[i] += ti;
+            }
+        }
+    }
+}
+
+static void fft_any(orc_cf32 *data, long n, int isign)
+{
+    long m = 1;
+    while (m < 2 * n - 1)
+        m <<= 1;
+    double *ar = (double *) calloc((size_t) m, sizeof(double)), *ai = (double *) calloc((size_t) m, sizeof(double));
+    double *br = (double *) calloc((size_t) m, sizeof(double)), *bi = (double *) calloc((size_t) m, sizeof(double));
+    double *wr = (double *) malloc(sizeof(double) * (size_t) n), *wi = (double *) malloc(sizeof(double) * (size_t) n);
+    for (long k = 0; k < n; k++) {                            /* w[k] = exp(isign*i*pi*k^2/n) */
+        const long long k2 = ((long long) k * k) % (2 * n);
+        const double a = isign * ORC_PI * (double) k2 / (double) n;
+        wr[k] = cos(a);
+        wi[k] = sin(a);
+        ar[k] = data[k].r * wr[k] - data[k].i * wi[k];
+        ai[k] = data[k].r * wi[k] + data[k].i * wr[k];
+        br[k] = wr[k];
+        bi[k] = -wi[k];
+        if (k) {
+            br[m - k] = wr[k];
+            bi[m - k] = -wi[k];
+        }
+    }
+    dfft_pow2(ar, ai, m, -1);
+    dfft_pow2(br, bi, m, -1);
+    for (long k = 0; k < m; k++) {
+        const double tr = ar[k] * br[k] - ai[k] * bi[k];
+        ai[k] = ar[k] * bi[k] + ai[k] * br[k];
+        ar[k] = tr;
+    }
+    dfft_pow2(ar, ai, m, +1);
+    for (long k = 0; k < n; k++) {
+        const double cr = ar[k] / (double) m, ci = ai[k] / (double) m;
+        data[k].r = (float) (cr * wr[k] - ci * wi[k]);
+        data[k].i = (float) (cr * wi[k] + ci * wr[k]);
+    }
+    free(ar); free(ai); free(br); free(bi); free(wr); free(wi);
+}
+
+void orc_fft(orc_cf32 *data, long n, int isign)
+{
+    if (n <= 1)
+        return;
+    if ((n & (n - 1)) == 0)
+        fft_pow2(data, n, isign);
+    else
+        fft_any(data, n, isign);
 }
 
 /* ------------------------------------------------------------------------

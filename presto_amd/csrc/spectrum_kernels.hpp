@@ -125,6 +125,76 @@ __global__ __launch_bounds__(256) void k_real_unpack(c32 *__restrict__ data, int
 }
 
 // ---------------------------------------------------------------------------
+// Lengths that are not powers of two: the chirp-z identity
+//   X[k] = w[k] * sum_j (x[j] w[j]) conj(w[k-j]),   w[k] = exp(-i*pi*k^2/L),
+// i.e. one circular convolution of length M >= 2L-1 (a power of two) done with
+// the long transforms above.  k^2 is reduced mod 2L in integers before the
+// phase is formed, so the chirp is exact to fp64 round-off at any k.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void chirp(int64_t k, int64_t L, double *c, double *s)
+{
+    const int64_t k2 = (k * k) % (2 * L);
+    sincospi(-(double) k2 / (double) L, s, c);
+}
+
+// a[k] = x[k] * w[k] (k < L), 0 up to M
+__global__ __launch_bounds__(256) void k_blu_pre(const c32 *__restrict__ x, c32 *__restrict__ a,
+                                                int64_t L, int64_t M)
+{
+    const int64_t k = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (k >= M)
+        return;
+    c32 v = c32{0.f, 0.f};
+    if (k < L) {
+        double c, s;
+        chirp(k, L, &c, &s);
+        const c32 d = x[k];
+        v = c32{(float) ((double) d.x * c - (double) d.y * s), (float) ((double) d.x * s + (double) d.y * c)};
+    }
+    a[k] = v;
+}
+
+// b[k] = conj(w[k]) for |k| < L (negative k wrapped to M - |k|), 0 elsewhere
+__global__ __launch_bounds__(256) void k_blu_filter(c32 *__restrict__ b, int64_t L, int64_t M)
+{
+    const int64_t k = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (k >= M)
+        return;
+    const int64_t j = k < L ? k : (M - k < L ? M - k : -1);
+    c32 v = c32{0.f, 0.f};
+    if (j >= 0) {
+        double c, s;
+        chirp(j, L, &c, &s);
+        v = c32{(float) c, (float) -s};
+    }
+    b[k] = v;
+}
+
+// a[k] = conj(a[k] * b[k]): the inverse transform is conj(FFT(conj(.))) / M
+__global__ __launch_bounds__(256) void k_blu_mul(c32 *__restrict__ a, const c32 *__restrict__ b, int64_t M)
+{
+    const int64_t k = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (k >= M)
+        return;
+    const c32 p = afft::cmul(a[k], b[k]);
+    a[k] = c32{p.x, -p.y};
+}
+
+// X[k] = w[k] * conj(c[k]) / M
+__global__ __launch_bounds__(256) void k_blu_post(const c32 *__restrict__ cbuf, c32 *__restrict__ X,
+                                                 int64_t L, int64_t M)
+{
+    const int64_t k = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (k >= L)
+        return;
+    double c, s;
+    chirp(k, L, &c, &s);
+    const double inv = 1.0 / (double) M;
+    const double re = (double) cbuf[k].x * inv, im = -(double) cbuf[k].y * inv;
+    X[k] = c32{(float) (re * c - im * s), (float) (re * s + im * c)};
+}
+
+// ---------------------------------------------------------------------------
 // Red-noise removal.
 // ---------------------------------------------------------------------------
 constexpr int kMaxRedBlock = 1024; // longest median block (16 values per lane)

@@ -53,9 +53,25 @@ def test_realfft_matches_oracle(gpu, oracle, log2n):
 def test_realfft_rejects_bad_lengths(gpu):
     import presto_amd as pa
     with pytest.raises(pa.AccelGPUError):
-        gpu.load_dat(np.zeros(3 * 4096, dtype=np.float32))
+        gpu.load_dat(np.zeros(4097, dtype=np.float32))          # odd
     with pytest.raises(pa.AccelGPUError):
-        gpu.load_dat(np.zeros(512, dtype=np.float32))
+        gpu.load_dat(np.zeros(512, dtype=np.float32))           # too short
+
+
+@pytest.mark.parametrize("n", [3000, 2 * 3 * 5 * 7 * 11 * 4, 100002, 3 * (1 << 17), 1000000, 5 * (1 << 20) + 2])
+def test_realfft_any_even_length(gpu, oracle, n):
+    """Lengths that are not powers of two go through the chirp-z convolution."""
+    x = _series(n, n % 97)
+    assert gpu.load_dat(x, deredden=False) == n // 2
+    got = gpu.get_fft(n // 2)
+    ref = np.fft.rfft(x.astype(np.float64))
+    rms = np.sqrt(np.mean(np.abs(ref[1:-1]) ** 2))
+    tol = 4e-6 * rms * np.sqrt(np.log2(n)) + 4e-7 * abs(ref[0].real)
+    assert abs(got[0].real - ref[0].real) <= 4e-6 * abs(ref[0].real)
+    assert np.abs(got[1:] - ref[1:-1]).max() <= tol
+    if n <= 200000:
+        want = oracle.realfft(x)
+        assert np.abs(got[1:] - want[1:]).max() <= tol
 
 
 @pytest.mark.parametrize("n", [1 << 12, 1 << 16, 1 << 20, (1 << 18) + 1234])
