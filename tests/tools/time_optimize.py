@@ -1,7 +1,8 @@
-"""Times candidate optimisation: GPU (one workgroup per candidate) vs the CPU oracle."""
+"""Times candidate optimisation: GPU (one workgroup per candidate) vs the CPU oracle.
+Lives under tests/ because it runs the oracle (test infrastructure)."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import presto_amd as pa
 from presto_amd import synth
 from oracle import binding as ob
