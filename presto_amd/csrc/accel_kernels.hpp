@@ -637,6 +637,133 @@ __global__ __launch_bounds__(256) void k_harmsum(
 
 
 // ---------------------------------------------------------------------------
+// The one-column-per-thread harmonic sum with the source-column bookkeeping
+// squeezed out of the vector registers, for many harmonics (where registers,
+// not bytes, limit the waves in flight).  Same sums, same order, same hits.
+//
+// A wave owns 64 consecutive columns rind = R0 + t (R0 wave-uniform, t the lane).
+// For harmonic h/2^s:  (rind*h + 2^(s-1)) >> s  =  Q + ((B + t*h) >> s)  with
+// A = R0*h + 2^(s-1), Q = A >> s, B = A & (2^s - 1): Q is scalar arithmetic done
+// at the moment of a reload, and the lane part is < 64, kept as a byte offset
+// (<= 252) in one byte of a packed register: NH/4 registers instead of NH.
+// ---------------------------------------------------------------------------
+constexpr int harm_stage_of(int i) // i-th sub-harmonic in summing order -> its stage s
+{
+    int s = 1;
+    while ((1 << s) - 1 <= i)
+        s++;
+    return s;
+}
+constexpr int harm_num_of(int i) // -> its odd numerator h
+{
+    const int s = harm_stage_of(i);
+    return 2 * (i + 1 - (1 << (s - 1))) + 1;
+}
+
+template <int NSTAGES, bool DUMP>
+__global__ __launch_bounds__(256) void k_harmsum_lean(
+    const float *__restrict__ plane, int64_t rlen, int numz, int64_t col0, int64_t ncols,
+    const int64_t *__restrict__ rowoff, const uint32_t *__restrict__ rowchg, HarmParams prm,
+    DevHit *__restrict__ hits, unsigned int *__restrict__ count, unsigned int max_hits,
+    float *__restrict__ dump, int dump_stage, int xcd_remap)
+{
+    constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
+    constexpr int NPK = (NH + 3) / 4 > 0 ? (NH + 3) / 4 : 1;
+    const int lane = threadIdx.x & 63;
+    unsigned int tile = blockIdx.x;
+    if (xcd_remap) {
+        const unsigned int per = (gridDim.x + 7) / 8;
+        tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int64_t c0 = (int64_t) tile * 256 + 64 * wave; // first column of this wave
+    if (c0 >= ncols)
+        return; // nothing to do for the whole wave (the kernel has no barriers)
+    const int64_t R0 = col0 + c0;
+    const bool live = c0 + lane < ncols;
+    const int t = live ? lane : 0; // dead lanes shadow the wave's first column
+
+    uint32_t pk[NPK];
+#pragma unroll
+    for (int q = 0; q < NPK; q++)
+        pk[q] = 0;
+#pragma unroll
+    for (int i = 0; i < NH; i++) {
+        const int s = harm_stage_of(i), h = harm_num_of(i);
+        const uint32_t B = (uint32_t) ((R0 * h + (1 << (s - 1))) & ((1 << s) - 1));
+        pk[i >> 2] |= (((B + (uint32_t) (t * h)) >> s) << 2) << (8 * (i & 3));
+    }
+
+    const char *pbytes = reinterpret_cast<const char *>(plane);
+    const uint32_t toff = 4u * (uint32_t) t;
+    float v[NHS];
+    for (int zi = 0; zi < numz; zi++) {
+        const char *frow = pbytes + 4 * ((size_t) zi * (size_t) rlen + (size_t) R0);
+        float p = *reinterpret_cast<const float *>(frow + toff);
+        const uint32_t chg = NH > 0 ? rowchg[zi] : 0u;
+        // the packed offsets must be unpacked at each use: hoisted out of the loop,
+        // the unpacked values would take the registers the packing saved
+#pragma unroll
+        for (int q = 0; q < NPK; q++)
+            asm volatile("" : "+v"(pk[q]));
+#pragma unroll
+        for (int i = 0; i < NH; i++) {
+            if (chg & (1u << i)) {
+                const int s = harm_stage_of(i), h = harm_num_of(i);
+                const int64_t Q = (R0 * h + (1 << (s - 1))) >> s;
+                const char *row = pbytes + rowoff[(size_t) zi * NHS + i] + 4 * Q;
+                v[i] = *reinterpret_cast<const float *>(row + ((pk[i >> 2] >> (8 * (i & 3))) & 0xFFu));
+            }
+        }
+        float ps[NSTAGES];
+        bool any = false;
+        {
+            int i = 0;
+#pragma unroll
+            for (int s = 0; s < NSTAGES; s++) {
+                if (s > 0) {
+#pragma unroll
+                    for (int h = 1; h < (1 << s); h += 2) {
+                        p += v[i];
+                        i++;
+                    }
+                }
+                ps[s] = p;
+                any |= live && (p > prm.powcut[s]);
+            }
+        }
+        if constexpr (DUMP) {
+#pragma unroll
+            for (int s = 0; s < NSTAGES; s++)
+                if (s == dump_stage && live)
+                    dump[(size_t) zi * ncols + (c0 + lane)] = ps[s];
+        } else {
+            if (__ballot(any)) { // rare: some lane of this wave crossed a threshold
+#pragma unroll
+                for (int s = 0; s < NSTAGES; s++) {
+                    const bool hit = live && (ps[s] > prm.powcut[s]);
+                    const unsigned long long mask = __ballot(hit);
+                    if (mask) {
+                        unsigned int base = 0;
+                        const int leader = __ffsll((long long) mask) - 1;
+                        if (lane == leader)
+                            base = atomicAdd(count, (unsigned int) __popcll(mask));
+                        base = __shfl(base, leader);
+                        if (hit) {
+                            const unsigned int pos =
+                                base + (unsigned int) __popcll(mask & ((1ull << lane) - 1ull));
+                            if (pos < max_hits)
+                                hits[pos] = DevHit{ps[s], ((uint32_t) s << 16) | (uint32_t) zi,
+                                                   R0 + lane};
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Block-granular forms of the same steps, for hosts that keep the reference's
 // per-block call sequence (one block of numz x USELEN powers at a time).
 // ---------------------------------------------------------------------------

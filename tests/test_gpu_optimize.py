@@ -206,3 +206,28 @@ def test_golden_optimised_candidates(gpu):
     out = gpu.optimize(kept)
     gold = p["opt"]
     _compare(gold, out)
+
+
+def test_wide_responses_match_oracle(gpu, oracle):
+    """|z| of hundreds to 1190: response half-widths of a thousand bins and more."""
+    import presto_amd as pa
+    numbins = 1 << 20
+    lines = [(334651.5, 1100.0, 40.0), (61520.25, -420.0, 25.0), (700000.0, -1190.0, 45.0), (20000.3, 150.0, 20.0)]
+    fft = synth.noise_fft(numbins, 22, lines=lines)
+    N, dt = 2 * numbins, 64e-6
+    c = np.zeros(len(lines), dtype=pa.CAND_DTYPE)
+    for i, (r, z, a) in enumerate(lines):
+        c[i] = (a * a, 30.0 - i, 1, 0, np.round(r * 2) / 2, 2 * np.round(z / 2))     # sigma descending
+    gpu.configure(numbins, N, dt, 1200, 1, fhi=1e9)
+    gpu.load_fft(fft)
+    s = oracle.Search(fft, N, dt, 20, 1, fhi=1e9, nthreads=8)      # the optimisation does not use the bank
+    for polish in (True, False):
+        go = gpu.optimize(c, polish=polish)
+        oo = s.optimize(c, polish=polish, eliminate=False)
+        for a, b in zip(oo, go):
+            assert a["r"] == b["r"] and a["z"] == b["z"]
+            assert abs(a["hirs"][0] - b["hirs"][0]) < 2e-3, (a["hirs"][0], b["hirs"][0])
+            assert abs(a["hizs"][0] - b["hizs"][0]) < 2e-2, (a["hizs"][0], b["hizs"][0])
+            assert abs(a["pows"][0] - b["pows"][0]) <= 1e-3 * a["pows"][0]
+            assert abs(a["derivs"][0]["locpow"] - b["derivs"][0]["locpow"]) <= 1e-3 * a["derivs"][0]["locpow"]
+    s.close()
