@@ -236,6 +236,15 @@ int accelgpu_sort_and_eliminate(accelgpu_cand *cands, int64_t n, int eliminate, 
  * max_rz_arr(), src/maximize_rz.c; amoeba(), src/amoeba.c. */
 int accelgpu_optimize_cands(accelgpu_ctx *ctx, const accelgpu_cand *cands, int64_t n, int polish,
                             accelgpu_optcand *out);
+/* The same in two halves, so that a host working through many trials keeps going while
+ * the device optimises: launch copies the candidates and queues the work, collect
+ * waits for it and fills out[0..n) (n as launched).  One optimisation at a time.
+ * With searches in flight (accelgpu_run_launch) both this pair and
+ * accelgpu_optimize_cands work on the spectrum of the search collected last, not on
+ * the one loaded for the next launch, and run beside the queued searches.
+ * ref: the per-candidate loop of src/accelsearch.c:240-254, one call at a time there. */
+int accelgpu_optimize_launch(accelgpu_ctx *ctx, const accelgpu_cand *cands, int64_t n, int polish);
+int accelgpu_optimize_collect(accelgpu_ctx *ctx, accelgpu_optcand *out, int64_t n);
 
 /* ref: fourierprops, include/presto.h:171-189 (88 bytes; the record of .cand files) */
 typedef struct accelgpu_fourierprops {
@@ -264,6 +273,21 @@ int accelgpu_nice_output(int error_digits, double val, double err, char *out, in
 int accelgpu_write_accel_files(const accelgpu_setup *setup, const accelgpu_optcand *cands,
                                int64_t n, float nph, const char *accel_path,
                                const char *cand_path, const char *inf_text);
+
+/* What the sifting step reads back from an ACCEL file for one fundamental, taken from
+ * the optimised candidate at the precision the file prints it with (so that a list
+ * built in memory equals one parsed from the file): sigma, summed and coherent power
+ * ("%.2f"), r and z (two error digits), and per harmonic the normalised power and the
+ * phase as their value(error) strings read.  Host only.
+ * ref: the parser of lib/python/sifting.py:1099-1200 over the table written by
+ * output_fundamentals()/output_harmonics(), src/accel_utils.c:565-835. */
+typedef struct accelgpu_siftrec {
+    double sigma, ipow, cpow, r, z;
+    int32_t numharm, pad;
+    double harm_pow[ACCELGPU_MAXHARM];
+    double harm_phs[ACCELGPU_MAXHARM];
+} accelgpu_siftrec;
+int accelgpu_sift_records(const accelgpu_optcand *cands, int64_t n, float nph, accelgpu_siftrec *out);
 
 /* ---- per-block forms (hosts that keep the reference's call sequence) ------ */
 /* Copies a host block (numz*USELEN floats, [z][r]) into the in-HBM plane at

@@ -87,6 +87,9 @@ def load_library():
     L.accelgpu_write_accel_files.argtypes = [pS, vp, i64, f, C.c_char_p, C.c_char_p, C.c_char_p]
     L.accelgpu_sort_and_eliminate.argtypes = [vp, i64, i, C.POINTER(i64)]
     L.accelgpu_optimize_cands.argtypes = [vp, vp, i64, i, vp]
+    L.accelgpu_sift_records.argtypes = [vp, i64, f, vp]
+    L.accelgpu_optimize_launch.argtypes = [vp, vp, i64, i]
+    L.accelgpu_optimize_collect.argtypes = [vp, vp, i64]
     L.accelgpu_set_search.argtypes = [vp, pS, i, f]
     L.accelgpu_set_block_range.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     L.accelgpu_fill_plane.argtypes = [vp]
@@ -149,6 +152,20 @@ FOURIERPROPS_DTYPE = np.dtype([("r", "f8"), ("rerr", "f4"), ("z", "f8"), ("zerr"
                                ("rawpow", "f4"), ("phs", "f4"), ("phserr", "f4"), ("cen", "f4"),
                                ("cenerr", "f4"), ("pur", "f4"), ("purerr", "f4"), ("locpow", "f4")],
                               align=True)
+
+
+SIFTREC_DTYPE = np.dtype([("sigma", "f8"), ("ipow", "f8"), ("cpow", "f8"), ("r", "f8"), ("z", "f8"),
+                          ("numharm", "i4"), ("_pad", "i4"), ("harm_pow", "f8", MAXHARM),
+                          ("harm_phs", "f8", MAXHARM)])
+
+
+def sift_records(optcands, nph=0.0):
+    """Per optimised candidate, the numbers the sifting step would read back from the
+    ACCEL file (printed precision): SIFTREC_DTYPE records."""
+    c = np.ascontiguousarray(optcands, dtype=OPTCAND_DTYPE)
+    out = np.zeros(c.size, dtype=SIFTREC_DTYPE)
+    _check(load_library().accelgpu_sift_records(_ptr(c), c.size, float(nph), _ptr(out)))
+    return out
 
 
 def nice_output(error_digits, val, err):
@@ -328,6 +345,18 @@ class AccelSearchGPU:
         c = np.ascontiguousarray(cands, dtype=CAND_DTYPE)
         out = np.zeros(c.size, dtype=OPTCAND_DTYPE)
         _check(self.L.accelgpu_optimize_cands(self._h, _ptr(c), c.size, int(bool(polish)), _ptr(out)))
+        return out
+
+    def optimize_launch(self, cands, polish=True):
+        """First half of optimize(): queue the device work and return."""
+        c = np.ascontiguousarray(cands, dtype=CAND_DTYPE)
+        _check(self.L.accelgpu_optimize_launch(self._h, _ptr(c), c.size, int(bool(polish))))
+        return c.size
+
+    def optimize_collect(self, n):
+        """Second half: wait and return the n OPTCAND_DTYPE records."""
+        out = np.zeros(int(n), dtype=OPTCAND_DTYPE)
+        _check(self.L.accelgpu_optimize_collect(self._h, _ptr(out), out.size))
         return out
 
     # -- standard (not in-memory) mode ---------------------------------------

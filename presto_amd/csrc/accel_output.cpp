@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -390,6 +391,78 @@ int write_accel_files(const accelgpu_setup *su, const accelgpu_optcand *cands, i
         return ACCELGPU_ERR_ARG;
     }
     fclose(f);
+    return ACCELGPU_OK;
+}
+
+namespace {
+
+// leading number of a value(error) string
+double leading_number(const std::string &t) { return std::strtod(t.c_str(), nullptr); }
+
+// '12.3(4)' or '1.2(3)x10^5' -> value; an exponent that does not read as a number counts as 5
+double printed_power(const std::string &t)
+{
+    double v = leading_number(t);
+    const size_t hat = t.find('^');
+    if (hat != std::string::npos) {
+        const char *b = t.c_str() + hat + 1;
+        char *e = nullptr;
+        double ex = std::strtod(b, &e);
+        while (e && (*e == ' ' || *e == '\t' || *e == '\n'))
+            e++;
+        if (e == b || (e && *e != '\0'))
+            ex = 5.0;
+        v *= std::pow(10.0, ex);
+    }
+    return v;
+}
+
+} // namespace
+
+int sift_records(const accelgpu_optcand *cands, int64_t n, float nph, accelgpu_siftrec *out)
+{
+    if (n < 0 || (n > 0 && (!cands || !out))) {
+        set_error("sift_records: bad arguments");
+        return ACCELGPU_ERR_ARG;
+    }
+    for (int64_t i = 0; i < n; i++) {
+        const accelgpu_optcand &c = cands[i];
+        accelgpu_siftrec &o = out[i];
+        memset(&o, 0, sizeof(o));
+        if (c.numharm < 1 || c.numharm > ACCELGPU_MAXHARM) {
+            set_error("sift_records: candidate %lld has numharm %d", (long long) i, c.numharm);
+            return ACCELGPU_ERR_ARG;
+        }
+        double cr = 0.0, ci = 0.0;
+        const double phs0 = c.derivs[0].phs;
+        bool ok = true;
+        for (int h = 0; h < c.numharm; h++) {
+            accelgpu_rderivs d = c.derivs[h];
+            const double amp = std::sqrt(d.pow / (nph > 0.0f ? (double) nph : d.locpow));
+            const double corr = phs0 - std::fmod((h + 1.0) * phs0, kTwoPi);
+            cr += amp * std::cos(d.phs + corr);
+            ci += amp * std::sin(d.phs + corr);
+            if (nph > 0.0f)
+                d.locpow = nph;
+            accelgpu_fourierprops q;
+            memset(&q, 0, sizeof(q));
+            int rc = calc_props(d, c.hirs[h], c.hizs[h], 0.0, &q);
+            if (rc)
+                return rc;
+            o.harm_pow[h] = printed_power(nice_output_2(q.pow, q.powerr, &ok));
+            o.harm_phs[h] = leading_number(nice_output_2(q.phs, q.phserr, &ok));
+        }
+        o.numharm = c.numharm;
+        o.sigma = leading_number(fmt("%.2f", c.sigma));
+        o.ipow = leading_number(fmt("%.2f", c.power));
+        o.cpow = leading_number(fmt("%.2f", cr * cr + ci * ci));
+        o.r = leading_number(nice_output_2(c.r, 0.5f / c.numharm, &ok));
+        o.z = leading_number(nice_output_2(c.z, 2.0f / c.numharm, &ok));
+        if (!ok) {
+            set_error("This is an undefined condition in nice_output2().");
+            return ACCELGPU_ERR_ARG;
+        }
+    }
     return ACCELGPU_OK;
 }
 

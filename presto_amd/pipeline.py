@@ -10,7 +10,10 @@ per DM trial, then `sifting` over all ACCEL files), as one program per GPU:
 Rank r takes files r, r+N, ... ; for each it loads the spectrum (or transforms the
 .dat time series on the device), optionally zaps and de-reddens it in HBM, searches,
 trims and optimises the candidates on the GPU and writes <root>_ACCEL_<zmax>,
-.cand and .txtcand exactly as the stand-alone program does.  The fundamentals of
+.cand and .txtcand exactly as the stand-alone program does.  The files move through
+a three-stage pipeline: a reader thread holds the next file in memory, the GPU
+searches the current one, and the host finishes the previous one (list replay,
+device optimisation beside the running search, result files).  The fundamentals of
 all files are then all-gathered (RCCL over xGMI; gloo on CPU) and rank 0 runs the
 cross-DM sifting and writes <out>.accelcands and <out>.report.
 """
@@ -22,6 +25,21 @@ import time
 import numpy as np
 
 from . import batch, sifting
+
+# seconds spent per step of the driver since the process started (diagnostics)
+TIMES = {}
+
+
+class _timed:
+    def __init__(self, key):
+        self.key = key
+
+    def __enter__(self):
+        self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        TIMES[self.key] = TIMES.get(self.key, 0.0) + time.perf_counter() - self.t0
+
 
 # one fixed-size record per fundamental for the exchange
 SIFT_FIELDS = ("file", "candnum", "sigma", "numharm", "ipow", "cpow", "r", "z", "snr", "dm")
@@ -42,50 +60,191 @@ def read_inf(root):
     return N, dt
 
 
-def search_one_file(gpu, path, opts):
-    """The whole accelsearch run on one file.  Returns the sifting Candlist of its
-    fundamentals (before any rejection) and the seconds spent."""
-    from . import api
-    t0 = time.perf_counter()
-    root, ext = os.path.splitext(path)
-    N, dt = read_inf(root)
-    T = N * dt
-    dat_input = ext in (".dat", ".sdat")
-    if ext == ".fft":
-        spec = np.fromfile(path, dtype=np.complex64)
-        numbins = spec.size
-    elif dat_input:
-        series = np.fromfile(path, dtype=np.int16 if ext == ".sdat" else np.float32).astype(np.float32)
-        numbins = series.size // 2
+class _Trial:
+    """One input file on its way through the GPU."""
+    __slots__ = ("index", "path", "root", "ext", "N", "dt", "data", "numbins", "setup", "t0", "nopt")
+
+
+def read_trial(index, path):
+    """Host side of the input: the .inf numbers and the samples (no GPU call; runs on the
+    reader thread, numpy releases the interpreter lock while it reads)."""
+    t = _Trial()
+    t.index, t.path, t.t0 = index, path, time.perf_counter()
+    t.root, t.ext = os.path.splitext(path)
+    t.N, t.dt = read_inf(t.root)
+    if t.ext == ".fft":
+        t.data = np.fromfile(path, dtype=np.complex64)
+        t.numbins = t.data.size
+    elif t.ext in (".dat", ".sdat"):
+        t.data = np.fromfile(path, dtype=np.int16 if t.ext == ".sdat" else np.float32).astype(np.float32)
+        t.numbins = t.data.size // 2
     else:
         raise ValueError("input file ('%s') must be an '.fft' or '.[s]dat' file" % path)
-    setup = gpu.configure(numbins, N, dt, opts.zmax, opts.numharm, sigma=opts.sigma, flo=opts.flo,
-                          fhi=opts.fhi, norm_type=1 if opts.locpow else 0)
-    if dat_input:
-        gpu.load_dat(series, deredden=True)
-    else:
-        gpu.load_fft(spec)
-    if opts.birds is not None:
-        gpu.zapbirds(*opts.birds(T))
-    if opts.rednoise and not dat_input:
-        gpu.rednoise(T)
-    hits, cands, sig, added = gpu.search()
-    if not dat_input:                       # the work file of the search (src/accel_utils.c:1291-1294)
-        with open("%s_ACCEL_%d.txtcand" % (root, setup.zmax), "w") as f:
-            for h, s in zip(hits[added != 0], sig[added != 0]):
-                nh = 1 << int(h["stage"])
-                rr = h["rind"] * 0.5 / nh
-                f.write("%-7.2f  %-7.4f  %-2d  %-14.4f  %-14.9f  %-10.4f\n" % (
-                    h["power"], s, nh, rr, rr / T, (setup.zlo + h["zind"] * 2.0) / nh))
-    accelnm = "%s_ACCEL_%d" % (root, setup.zmax)
-    if len(cands) == 0:
-        return sifting.Candlist([]), time.perf_counter() - t0
-    kept = api.sort_and_eliminate(cands, eliminate=opts.numharm > 1 and not opts.noharmremove)
-    opt = gpu.optimize(kept, polish=not opts.noharmpolish)
-    api.write_accel_files(setup, opt, accelnm, accelnm + ".cand", open(root + ".inf").read())
-    m = sifting.DM_re.search(accelnm)
-    cl = sifting.candlist_from_optcands(opt, setup, m.groups()[0] if m else "0.00", accelnm)
-    return cl, time.perf_counter() - t0
+    return t
+
+
+def _geometry(t, opts):
+    return (t.numbins, t.N, t.dt, opts.zmax, opts.numharm, opts.sigma, opts.flo, opts.fhi, bool(opts.locpow))
+
+
+def stage_trial(gpu, t, opts, state):
+    """Upload, prepare and launch one trial.  Everything here runs beside a search that
+    is still in flight (the library keeps several spectrum buffers); only a change of
+    the search geometry needs the GPU drained first, which the caller does."""
+    geo = _geometry(t, opts)
+    if state.get("geometry") != geo:
+        state["setup"] = gpu.configure(t.numbins, t.N, t.dt, opts.zmax, opts.numharm, sigma=opts.sigma,
+                                       flo=opts.flo, fhi=opts.fhi, norm_type=1 if opts.locpow else 0)
+        state["geometry"] = geo
+    t.setup = state["setup"]
+    T = t.N * t.dt
+    dat_input = t.ext != ".fft"
+    with _timed("upload+prepare"):
+        if dat_input:
+            gpu.load_dat(t.data, deredden=True)
+        else:
+            gpu.load_fft(t.data)
+        t.data = None
+        if opts.birds is not None:
+            gpu.zapbirds(*opts.birds(T))
+        if opts.rednoise and not dat_input:
+            gpu.rednoise(T)
+    with _timed("launch"):
+        gpu.run_launch()
+
+
+def collect_trial(gpu, t, opts):
+    """First part of what follows a launch: collect the hits, replay the candidate list,
+    write the work file, trim the list and queue its optimisation on the device (against
+    this trial's spectrum, beside the next trial's search)."""
+    from . import api
+    setup = t.setup
+    T = t.N * t.dt
+    with _timed("collect"):
+        hits = gpu.run_collect(max_hits=1 << 18)
+    with _timed("replay"):
+        cands, sig, added = api.replay_candidates(setup, hits)
+    accelnm = "%s_ACCEL_%d" % (t.root, setup.zmax)
+    if t.ext == ".fft":                     # the work file of the search (src/accel_utils.c:1291-1294)
+        with _timed("txtcand"):
+            sel = added != 0
+            h, s = hits[sel], sig[sel]
+            nh = 1 << h["stage"].astype(np.int64)
+            rr = h["rind"] * 0.5 / nh
+            zz = (setup.zlo + h["zind"] * 2.0) / nh
+            with open(accelnm + ".txtcand", "w") as f:
+                f.write("".join("%-7.2f  %-7.4f  %-2d  %-14.4f  %-14.9f  %-10.4f\n" % row
+                                for row in zip(h["power"].tolist(), s.tolist(), nh.tolist(), rr.tolist(),
+                                               (rr / T).tolist(), zz.tolist())))
+    t.nopt = 0
+    if len(cands):
+        with _timed("optimize launch"):
+            kept = api.sort_and_eliminate(cands, eliminate=opts.numharm > 1 and not opts.noharmremove)
+            t.nopt = gpu.optimize_launch(kept, polish=not opts.noharmpolish)
+
+
+def write_trial(gpu, t, opts, writer=None):
+    """Second part: wait for the optimisation, write <root>_ACCEL_<zmax> and .cand, and
+    return the sifting Candlist of the trial's fundamentals (before any rejection); with
+    a `writer` executor the files are written there and a future is returned."""
+    from . import api
+    setup = t.setup
+    accelnm = "%s_ACCEL_%d" % (t.root, setup.zmax)
+    opt = None
+    if t.nopt:
+        with _timed("optimize wait"):
+            opt = gpu.optimize_collect(t.nopt)
+
+    def write_results():
+        if opt is None:
+            return sifting.Candlist([])
+        with _timed("result files"):
+            with open(t.root + ".inf") as f:
+                inf_text = f.read()
+            api.write_accel_files(setup, opt, accelnm, accelnm + ".cand", inf_text)
+            m = sifting.DM_re.search(accelnm)
+            return sifting.candlist_from_optcands(opt, setup, m.groups()[0] if m else "0.00", accelnm)
+    return write_results() if writer is None else writer.submit(write_results)
+
+
+def search_one_file(gpu, path, opts):
+    """The whole accelsearch run on one file, start to end.  Returns the Candlist of its
+    fundamentals and the seconds spent."""
+    t = read_trial(0, path)
+    stage_trial(gpu, t, opts, {})
+    collect_trial(gpu, t, opts)
+    cl = write_trial(gpu, t, opts)
+    return cl, time.perf_counter() - t.t0
+
+
+def search_files(gpu, files, indices, opts, depth=2):
+    """Generator over (index, Candlist, seconds since the previous result) for the files
+    `indices`, as a three-stage pipeline: a reader thread has the next file in memory
+    while the GPU searches the current one and the host finishes the previous one."""
+    import queue
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    q = queue.Queue(maxsize=depth)
+
+    def reader():
+        try:
+            for i in indices:
+                q.put(read_trial(i, files[i]))
+            q.put(None)
+        except BaseException as e:          # hand the failure to the consumer
+            q.put(e)
+
+    th = threading.Thread(target=reader, daemon=True)
+    th.start()
+    writer = ThreadPoolExecutor(max_workers=1)      # result files, off the launch path
+    state = {}
+    launched = None                                 # trial whose search is queued or running
+    optimising = None                               # trial whose candidates are being optimised
+    last = time.perf_counter()
+    written = []                                    # (index, future of the Candlist), in order
+
+    def ready(all_of_them=False):
+        nonlocal last
+        while written and (all_of_them or written[0][1].done()):
+            i, fut = written.pop(0)
+            cl = fut.result()
+            now = time.perf_counter()
+            yield i, cl, now - last
+            last = now
+
+    def advance():
+        """One step for the trials behind the newest launch: results of the older
+        optimisation out to the writer, the collected search's candidates to the device."""
+        nonlocal launched, optimising
+        if optimising is not None:
+            written.append((optimising.index, write_trial(gpu, optimising, opts, writer)))
+            optimising = None
+        if launched is not None:
+            collect_trial(gpu, launched, opts)
+            optimising, launched = launched, None
+
+    try:
+        while True:
+            with _timed("wait for reader"):
+                t = q.get()
+            if isinstance(t, BaseException):
+                raise t
+            if t is None:
+                break
+            if launched is not None and state.get("geometry") != _geometry(t, opts):
+                advance()                           # a new geometry rebuilds the plane: drain first
+            prev, launched = launched, None
+            stage_trial(gpu, t, opts, state)        # queued behind prev's search on the GPU
+            launched = prev
+            advance()                               # host work and optimisation overlap t's search
+            launched = t
+            yield from ready()
+        advance()
+        advance()
+        yield from ready(all_of_them=True)
+    finally:
+        writer.shutdown(wait=True)
+    th.join()
 
 
 def candlist_to_records(cl, file_index):
@@ -126,8 +285,17 @@ def sift(candlist, dmstrs, min_dm_hits=2, low_dm_cutoff=2.0, verbosity=1):
 
 
 def make_bird_fn(zaplist, baryv):
+    """T -> (lobins, hibins) of the zap list, read once per observation length."""
+    if not zaplist:
+        return None
     from . import api
-    return (lambda T: api.read_birds(zaplist, T, baryv)) if zaplist else None
+    cache = {}
+
+    def birds(T):
+        if T not in cache:
+            cache[T] = api.read_birds(zaplist, T, baryv)
+        return cache[T]
+    return birds
 
 
 def run(files, opts, rank=0, world=1, device=0, gather=None):
@@ -137,8 +305,7 @@ def run(files, opts, rank=0, world=1, device=0, gather=None):
     mine = batch.shard_trials(len(files), rank, world)
     gpu = api.AccelSearchGPU(device)
     recs, secs, Ts = [], [], {}
-    for i in mine:
-        cl, dt_s = search_one_file(gpu, files[i], opts)
+    for i, cl, dt_s in search_files(gpu, files, mine, opts):
         recs.append(candlist_to_records(cl, i))
         secs.append(dt_s)
     gpu.close()

@@ -506,32 +506,13 @@ def candlist_from_optcands(optcands, setup, DMstr, filename, nph=0.0, trackbad=F
     from . import api
     tobs = setup.T
     cands = []
-    for i, c in enumerate(optcands):
-        nh = int(c["numharm"])
-        phs0 = c["derivs"][0]["phs"]
-        cr = ci = 0.0
-        pows = np.zeros(nh)
-        phases = np.zeros(nh)
-        for h in range(nh):
-            d = c["derivs"][h]
-            loc = nph if nph > 0 else d["locpow"]
-            amp = np.sqrt(d["pow"] / loc)
-            corr = phs0 - np.fmod((h + 1.0) * phs0, 2 * np.pi)
-            cr += amp * np.cos(d["phs"] + corr)
-            ci += amp * np.sin(d["phs"] + corr)
-            dd = np.array(d).copy()
-            if nph > 0:
-                dd["locpow"] = nph
-            q = api.calc_props(dd, c["hirs"][h], c["hizs"][h])
-            pows[h] = parse_power(api.nice_output(2, q["pow"], q["powerr"]))
-            phases[h] = float(api.nice_output(2, q["phs"], q["phserr"]).split("(")[0])
-        rerr, zerr = np.float32(0.5) / nh, np.float32(2.0) / nh
-        cand = Candidate(i + 1, float("%.2f" % c["sigma"]), nh, float("%.2f" % c["power"]),
-                         float("%.2f" % (cr * cr + ci * ci)),
-                         float(api.nice_output(2, c["r"], rerr).split("(")[0]),
-                         float(api.nice_output(2, c["z"], zerr).split("(")[0]), DMstr, filename, tobs)
+    for i, q in enumerate(api.sift_records(optcands, nph)):
+        nh = int(q["numharm"])
+        cand = Candidate(i + 1, float(q["sigma"]), nh, float(q["ipow"]), float(q["cpow"]), float(q["r"]),
+                         float(q["z"]), DMstr, filename, tobs)
+        pows = np.array(q["harm_pow"][:nh])
         cand.harm_pows = pows
-        cand.harm_amps = (np.sqrt(pows) * np.exp(phases * 1.0j)).astype(np.complex64)
+        cand.harm_amps = (np.sqrt(pows) * np.exp(q["harm_phs"][:nh] * 1.0j)).astype(np.complex64)
         _finish(cand)
         cands.append(cand)
     return Candlist(cands, trackbad=trackbad, trackdupes=trackdupes)

@@ -1,0 +1,34 @@
+"""End-to-end rate of the batch driver on one GPU: DM-trial .fft files on local disk ->
+search -> optimisation -> ACCEL/.cand/.txtcand files -> sifting."""
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from presto_amd import pipeline, synth       # noqa: E402
+
+nfiles = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+ndistinct = min(nfiles, 8)
+cfg = dict(synth.CONFIGS["cfg2"])
+tmp = tempfile.mkdtemp(prefix="pipe_", dir="/tmp")
+files = []
+for k in range(nfiles):
+    root = os.path.join(tmp, "beam_DM%.2f" % (10.0 + k))
+    if k < ndistinct:
+        spec = synth.make_fft(cfg["N"], cfg["dt"], cfg["pulsars"], seed=1000 + k)
+        specs = specs + [spec] if k else [spec]
+    synth.write_fft(root, specs[k % ndistinct], cfg["N"], cfg["dt"])
+    files.append(root + ".fft")
+opts = pipeline.parse_args(["-zmax", "200", "-numharm", "16", "-fhi", "1e9", "-verbosity", "0",
+                            "-o", os.path.join(tmp, "beam")] + files)
+for rep in range(2):
+    t0 = time.perf_counter()
+    cl, secs = pipeline.run(sorted(files), opts)
+    dt = time.perf_counter() - t0
+    print("pass %d: %d files in %.3f s = %.1f files/s; per file %s ms; %d sifted candidates" % (
+        rep, nfiles, dt, nfiles / dt, " ".join("%.1f" % (1e3 * s) for s in secs), len(cl)))
+    print("    ms per file: " + "  ".join("%s %.2f" % (k, 1e3 * v / nfiles) for k, v in pipeline.TIMES.items()))
+    pipeline.TIMES.clear()
