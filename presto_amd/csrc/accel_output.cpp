@@ -449,15 +449,16 @@ int sift_records(const accelgpu_optcand *cands, int64_t n, float nph, accelgpu_s
             int rc = calc_props(d, c.hirs[h], c.hizs[h], 0.0, &q);
             if (rc)
                 return rc;
-            o.harm_pow[h] = printed_power(nice_output_2(q.pow, q.powerr, &ok));
-            o.harm_phs[h] = leading_number(nice_output_2(q.phs, q.phserr, &ok));
+            o.harm_pow[h] = printed_power(centred(nice_output_2(q.pow, q.powerr, &ok), 15));
+            o.harm_phs[h] = leading_number(centred(nice_output_2(q.phs, q.phserr, &ok), 12));
         }
         o.numharm = c.numharm;
-        o.sigma = leading_number(fmt("%.2f", c.sigma));
-        o.ipow = leading_number(fmt("%.2f", c.power));
-        o.cpow = leading_number(fmt("%.2f", cr * cr + ci * ci));
-        o.r = leading_number(nice_output_2(c.r, 0.5f / c.numharm, &ok));
-        o.z = leading_number(nice_output_2(c.z, 2.0f / c.numharm, &ok));
+        // each cell as the table holds it: centred in its column and cut at the column's width
+        o.sigma = leading_number(centred(fmt("%.2f", c.sigma), 5));
+        o.ipow = leading_number(centred(fmt("%.2f", c.power), 6));
+        o.cpow = leading_number(centred(fmt("%.2f", cr * cr + ci * ci), 8));
+        o.r = leading_number(centred(nice_output_2(c.r, 0.5f / c.numharm, &ok), 15));
+        o.z = leading_number(centred(nice_output_2(c.z, 2.0f / c.numharm, &ok), 11));
         if (!ok) {
             set_error("This is an undefined condition in nice_output2().");
             return ACCELGPU_ERR_ARG;

@@ -1,0 +1,116 @@
+"""Overlapped use of one context: the next trial is uploaded, prepared and launched while
+a search is in flight, and the candidates of the search collected last are optimised
+against their own spectrum beside the queued searches.  Everything must equal the plain
+one-after-the-other sequence bit for bit (same kernels, same inputs)."""
+import numpy as np
+import pytest
+
+import presto_amd as pa
+from presto_amd import synth
+from presto_amd.api import replay_candidates, sort_and_eliminate
+
+pytestmark = pytest.mark.gpu
+N, DT, ZMAX, NH = 1 << 20, 1e-4, 20, 8
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    g = pa.AccelSearchGPU(0)
+    yield g
+    g.close()
+
+
+def _spectra():
+    out = []
+    for k, (f, z) in enumerate([(123.456, 3.0), (77.7, -11.0), (301.3, 0.0), (19.19, 8.0)]):
+        out.append(synth.make_fft(N, DT, [dict(f=f, z=z, amp=0.25, duty=0.08)], seed=70 + k))
+    return out
+
+
+def _plain(gpu, setup, spec, birds=None):
+    gpu.load_fft(spec)
+    if birds:
+        gpu.zapbirds(*birds)
+    hits = gpu.run()
+    cands, _, _ = replay_candidates(setup, hits)
+    kept = sort_and_eliminate(cands)
+    return hits, kept, gpu.optimize(kept)
+
+
+def test_overlapped_sequence_equals_plain_sequence(gpu):
+    specs = _spectra()
+    setup = gpu.configure(N // 2, N, DT, ZMAX, NH, fhi=4000.0)
+    birds = (np.array([5000.0, 12000.0]), np.array([5010.0, 12040.0]))
+    want = [_plain(gpu, setup, s, birds if k == 1 else None) for k, s in enumerate(specs)]
+
+    got = []
+    gpu.load_fft(specs[0])
+    gpu.run_launch()
+    pending = None
+    for k in range(len(specs)):
+        if k + 1 < len(specs):                       # next trial in while trial k is searched
+            gpu.load_fft(specs[k + 1])
+            if k + 1 == 1:
+                gpu.zapbirds(*birds)
+            gpu.run_launch()
+        hits = gpu.run_collect()
+        cands, _, _ = replay_candidates(setup, hits)
+        kept = sort_and_eliminate(cands)
+        if pending is not None:
+            got[-1].append(gpu.optimize_collect(pending))
+        pending = gpu.optimize_launch(kept)          # against trial k's spectrum, trial k+1 in flight
+        got.append([hits, kept])
+    got[-1].append(gpu.optimize_collect(pending))
+
+    for (h0, k0, o0), (h1, k1, o1) in zip(want, got):
+        assert len(h0) > 0 and np.array_equal(h0, h1)
+        assert np.array_equal(k0, k1)
+        assert len(o0) > 0 and o0.tobytes() == o1.tobytes()
+
+
+def test_blocking_optimize_with_a_search_in_flight(gpu):
+    specs = _spectra()
+    setup = gpu.configure(N // 2, N, DT, ZMAX, NH, fhi=4000.0)
+    h0, k0, o0 = _plain(gpu, setup, specs[0])
+    gpu.load_fft(specs[0])
+    gpu.run_launch()
+    gpu.load_fft(specs[1])
+    gpu.run_launch()
+    hits = gpu.run_collect()
+    assert np.array_equal(hits, h0)
+    assert gpu.optimize(k0).tobytes() == o0.tobytes()       # specs[1] is loaded and in flight
+    gpu.run_collect()
+
+
+def test_misuse_is_refused(gpu):
+    specs = _spectra()
+    setup = gpu.configure(N // 2, N, DT, ZMAX, NH, fhi=4000.0)
+    h0, k0, o0 = _plain(gpu, setup, specs[0])
+    gpu.load_fft(specs[0])
+    gpu.run_launch()
+    # a search is in flight and this context has collected none since: which spectrum?
+    gpu.load_fft(specs[1])
+    gpu.run_launch()
+    gpu.run_collect()                                       # specs[0] collected, specs[1] in flight
+    n = gpu.optimize_launch(k0)
+    with pytest.raises(pa.AccelGPUError):
+        gpu.optimize_launch(k0)                             # one optimisation at a time
+    with pytest.raises(pa.AccelGPUError):
+        gpu.optimize_collect(n + 1)                         # as many as were launched
+    assert gpu.optimize_collect(n).tobytes() == o0.tobytes()
+    with pytest.raises(pa.AccelGPUError):
+        gpu.optimize_collect(n)                             # nothing launched
+    with pytest.raises(pa.AccelGPUError):
+        gpu.zapbirds(np.array([10.0]), np.array([12.0]))    # would change what a launched search reads
+    gpu.load_fft(specs[2])
+    gpu.run_launch()                                        # specs[1], specs[2] in flight
+    with pytest.raises(pa.AccelGPUError):
+        gpu.run_launch()                                    # two at most
+    gpu.load_fft(specs[3])                                  # takes the buffer of the collected specs[0]
+    with pytest.raises(pa.AccelGPUError):
+        gpu.optimize(k0)                                    # its spectrum is gone
+    gpu.run_collect()
+    gpu.run_collect()
+    # drained: everything works again
+    h3, k3, o3 = _plain(gpu, setup, specs[3])
+    assert len(h3) > 0

@@ -59,6 +59,46 @@ def test_file_round_trip_and_in_memory_route(tmp_path):
         assert str(a) == str(b)
 
 
+@pytest.mark.parametrize("nph", [0.0, 3.5e4])
+def test_in_memory_route_equals_file_route_on_random_candidates(tmp_path, nph):
+    """Every number the consumer reads, over five decades of power (plain and x10^n
+    notation), negative z, up to 32 harmonics."""
+    import presto_amd as pa
+    import presto_amd.api as api
+    N, dt = 1 << 23, 64e-6
+    setup = pa.plan(N // 2, N, dt, 200, 32, fhi=1e9)
+    rng = np.random.default_rng(11)
+    n = 60
+    c = np.zeros(n, dtype=api.OPTCAND_DTYPE)
+    c["numharm"] = 2 ** rng.integers(0, 6, n)
+    c["r"] = np.sort(rng.uniform(300, 3e6, n)) / c["numharm"]
+    c["r"] = np.round(c["r"] * 2 * c["numharm"]) / (2 * c["numharm"])
+    c["z"] = rng.integers(-100, 100, n) * 2.0 / c["numharm"]
+    c["power"] = rng.uniform(20, 4000, n)
+    c["sigma"] = rng.uniform(2, 60, n)
+    for i in range(n):
+        nh = int(c["numharm"][i])
+        c["hirs"][i, :nh] = (c["r"][i] + rng.uniform(-0.2, 0.2)) * np.arange(1, nh + 1)
+        c["hizs"][i, :nh] = (c["z"][i] + rng.uniform(-0.5, 0.5)) * np.arange(1, nh + 1)
+        d = c["derivs"][i]
+        d["locpow"][:nh] = rng.uniform(0.5, 2.0, nh) * (nph if nph else 1.0)
+        d["pow"][:nh] = d["locpow"][:nh] * 10.0 ** rng.uniform(-0.5, 5.5, nh)
+        d["phs"][:nh] = rng.uniform(0, 2 * np.pi, nh)
+        d["dphs"][:nh] = rng.uniform(-3, 3, nh)
+        d["d2pow"][:nh] = -d["pow"][:nh] * rng.uniform(0.5, 8, nh)
+    name = str(tmp_path / "rand_DM33.00_ACCEL_200")
+    api.write_accel_files(setup, c, name, name + ".cand", synth.inf_text("rand_DM33.00", N, dt), nph=nph)
+    assert "x10^" in open(name).read()
+    cl = sifting.candlist_from_candfile(name)
+    mem = sifting.candlist_from_optcands(c, setup, "33.00", name, nph=nph)
+    assert len(cl) == len(mem) == n
+    for a, b in zip(cl, mem):
+        assert (a.candnum, a.numharm, a.r, a.z, a.ipow_det, a.cpow, a.sigma, a.snr, a.DM, a.T) == \
+               (b.candnum, b.numharm, b.r, b.z, b.ipow_det, b.cpow, b.sigma, b.snr, b.DM, b.T)
+        assert np.array_equal(a.harm_pows, b.harm_pows) and np.array_equal(a.harm_amps, b.harm_amps)
+        assert a.hits == b.hits and str(a) == str(b)
+
+
 def test_sift_across_dm_trials(tmp_path):
     sifting.r_err, sifting.sigma_threshold = 1.1, 6.0
     dms = [0.0, 2.5, 5.0, 7.5, 10.0]
