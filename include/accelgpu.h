@@ -112,7 +112,11 @@ int accelgpu_get_kernel(accelgpu_ctx *ctx, int zind, float *out_complex);
 
 /* ---- input spectrum ----------------------------------------------------- */
 /* Uploads numbins complex floats (PRESTO .fft layout); bin 0 of the array is
- * Fourier bin `lobin`.  ref: the mmap of the .fft, src/accel_utils.c:1497-1522,
+ * Fourier bin `lobin`.  The spectrum becomes the one the next launch reads.  The
+ * library keeps several spectrum buffers: with searches in flight
+ * (accelgpu_run_launch) the upload goes to one they do not read and runs beside
+ * them, as do the in-place steps below on a spectrum loaded that way.
+ * ref: the mmap of the .fft, src/accel_utils.c:1497-1522,
  * and get_fourier_amplitudes(), :848-877. */
 int accelgpu_load_fft(accelgpu_ctx *ctx, const float *fft_complex_host, int64_t numbins);
 /* Same, for a spectrum already in device memory (not copied, not owned). */
@@ -196,7 +200,10 @@ int accelgpu_run(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits, int64_
 
 /* Asynchronous halves of accelgpu_run() for pipelined batches: _launch queues
  * all GPU work of one trial on the stream and returns; _collect waits for it
- * and returns the sorted hits. */
+ * and returns the sorted hits.  At most two launches are in flight; they are
+ * collected in launch order.  A launched search keeps reading the spectrum that
+ * was current at its launch: in-place changes of that spectrum are refused until
+ * it is collected, loading another one is not. */
 int accelgpu_run_launch(accelgpu_ctx *ctx);
 int accelgpu_run_collect(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits,
                          int64_t *n_hits);
