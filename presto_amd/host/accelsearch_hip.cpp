@@ -62,7 +62,8 @@ int main(int argc, char **argv)
 {
     int zmax = 200, numharm = 8, device = 0, norm_type = 0;
     long long lobin = 0;
-    double sigma = 2.0, flo = 1.0, fhi = 10000.0;
+    double sigma = 2.0, flo = 1.0, fhi = 10000.0, baryv = 0.0;
+    std::string zaplist;
     bool photon = false, force_inmem = false, force_standard = false, polish = true, harmremove = true;
     std::string infile;
     for (int i = 1; i < argc; i++) {
@@ -80,7 +81,11 @@ int main(int argc, char **argv)
         else if (a == "-flo") flo = atof(need("-flo"));
         else if (a == "-fhi") fhi = atof(need("-fhi"));
         else if (a == "-lobin") lobin = atoll(need("-lobin"));
-        else if (a == "-rlo" || a == "-rhi" || a == "-ncpus" || a == "-baryv") (void) need(a.c_str());
+        // -rlo/-rhi never take effect in the reference either: its parser marks -flo and
+        // -fhi as always present, and they win (src/accel_utils.c:1581-1624)
+        else if (a == "-rlo" || a == "-rhi" || a == "-ncpus") (void) need(a.c_str());
+        else if (a == "-zaplist") zaplist = need("-zaplist");
+        else if (a == "-baryv") baryv = atof(need("-baryv"));
         else if (a == "-device") device = atoi(need("-device"));
         else if (a == "-photon") photon = true;
         else if (a == "-locpow") norm_type = 1;
@@ -104,6 +109,10 @@ int main(int argc, char **argv)
     if (!dat_input && !ends_with(".fft")) {
         // src/accel_utils.c:1397-1422
         printf("\nInput file ('%s') must be an '.fft' or '.[s]dat' file!\n\n", infile.c_str());
+        return 1;
+    }
+    if (baryv < -0.1 || baryv > 0.1) {
+        printf("\n-baryv must be in -0.1..0.1\n\n");
         return 1;
     }
     if (zmax < 0 || zmax > 1200 || sigma < 1.0 || sigma > 30.0) {
@@ -179,6 +188,26 @@ int main(int argc, char **argv)
         printf("Removing red-noise...");
         if (accelgpu_deredden(gpu)) die("accelgpu_deredden");
         printf("done.\n\n");
+        // Birdie zapping applies to a spectrum made in memory from a time series only
+        // (src/accelsearch.c:82-105); ranges are cut at the Nyquist bin as there.
+        if (!zaplist.empty()) {
+            int32_t nb = 0;
+            std::vector<double> lo(1), hi(1);
+            int zrc = accelgpu_read_birds(zaplist.c_str(), su.T, baryv, lo.data(), hi.data(), 0, &nb);
+            if (zrc == ACCELGPU_ERR_OVERFLOW) {
+                lo.resize((size_t) nb);
+                hi.resize((size_t) nb);
+                zrc = accelgpu_read_birds(zaplist.c_str(), su.T, baryv, lo.data(), hi.data(), nb, &nb);
+            }
+            if (zrc) die("accelgpu_read_birds");
+            printf("Zapping them using a barycentric velocity of %.5gc.\n\n", baryv);
+            const double hibin = (double) ((long long) Nd / 2);
+            int32_t use = 0;
+            for (; use < nb && lo[(size_t) use] < hibin; use++)
+                if (hi[(size_t) use] >= hibin)
+                    hi[(size_t) use] = hibin - 1;
+            if (accelgpu_zapbirds(gpu, lo.data(), hi.data(), use)) die("accelgpu_zapbirds");
+        }
         // The reference reads the photon count from bin 0 after de-reddening has
         // set it to 1 (src/accel_utils.c:1313, 1531-1533): so does this.
         if (photon) nph = 1.0f;

@@ -151,3 +151,44 @@ def test_command_line_dat_input(tmp_path):
     first = [l for l in out.splitlines() if l.startswith("sigma:")][0]
     assert "r: %-14.4f" % best["r"] in first and "harm: %-2d" % best["numharm"] in first
     assert abs(best["r"] / (N * dt) - 41.7) < 0.01 * 4
+
+
+def test_command_line_zaplist_on_dat_input(tmp_path):
+    """-zaplist/-baryv zap the spectrum made from a time series (src/accelsearch.c:82-105):
+    the zapped tone disappears from the ACCEL file, the pulsar stays, and the candidates
+    equal the library path with the same steps."""
+    import presto_amd as pa
+    import presto_amd.api as api
+    from presto_amd import sifting
+    exe = os.path.join(ROOT, "presto_amd", "host", "accelsearch_hip")
+    N, dt, zmax, numharm = 1 << 19, 5e-4, 20, 4
+    T = N * dt
+    x = synth.pulsar_series(N, dt, [dict(f=41.7, z=3.0, amp=0.4, duty=0.05),
+                                    dict(f=60.0, z=0.0, amp=0.8, duty=0.5)], seed=12).astype(np.float32)
+    root = str(tmp_path / "zap_DM3.00")
+    x.tofile(root + ".dat")
+    open(root + ".inf", "w").write(synth.inf_text(os.path.basename(root), N, dt))
+    zap = tmp_path / "mains.zaplist"
+    zap.write_text("# freq width\n60.0 0.5\n120.0 0.5\n180.0 0.5\nB900.0 5000.0\n")   # the last one runs past Nyquist
+    args = [exe, "-zmax", str(zmax), "-numharm", str(numharm), "-sigma", "4"]
+    subprocess.check_output(args + [root + ".dat"], timeout=170)
+    plain = sifting.candlist_from_candfile(root + "_ACCEL_20")
+    assert any(abs(c.f - 60.0) < 0.05 for c in plain)
+    out = subprocess.check_output(args + ["-zaplist", str(zap), "-baryv", "1e-4", root + ".dat"], timeout=170).decode()
+    assert "Zapping them using a barycentric velocity of 0.0001c." in out
+    zapped = sifting.candlist_from_candfile(root + "_ACCEL_20")
+    assert not any(abs(c.f - 60.0 * k) < 0.2 for c in zapped for k in (1, 2, 3))
+    assert any(abs(c.f - 41.7) < 0.02 for c in zapped)
+    # library path, same steps
+    g = pa.AccelSearchGPU(0)
+    g.configure(N // 2, N, dt, zmax, numharm, sigma=4.0)
+    g.load_dat(x, deredden=True)
+    lo, hi = api.read_birds(str(zap), T, 1e-4)
+    keep = lo < N // 2
+    g.zapbirds(lo[keep], np.minimum(hi[keep], N // 2 - 1))
+    hits, cands, sig, added = g.search()
+    kept = api.sort_and_eliminate(cands)
+    g.close()
+    assert len(kept) == len(zapped)
+    assert [c.numharm for c in zapped] == list(kept["numharm"])
+    assert np.allclose([c.r for c in zapped], kept["r"], atol=0.26)
