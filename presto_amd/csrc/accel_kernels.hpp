@@ -848,6 +848,48 @@ __global__ __launch_bounds__(256) void k_add_sub(float *__restrict__ fund,
         sub[((size_t) zind[zi] * nb + b) * sub_stride + src];
 }
 
+// One harmonic stage of the standard mode in one pass over the fundamental blocks: the
+// NS sub-harmonics of the stage are added in the reference's order (harmnum 1, 3, 5, ...,
+// each its own float add), the sum is stored and scanned against the stage's threshold.
+// Sub-harmonic s lives at sub + s*sub_elems ([z][block][sub_stride]), its column table at
+// rinds + s*rinds_elems ([block][USELEN]) and its row table at zind + s*numz.
+template <int NS>
+__global__ __launch_bounds__(256) void k_add_stage(
+    float *__restrict__ fund, const float *__restrict__ sub, size_t sub_elems, int sub_stride,
+    const unsigned short *__restrict__ rinds, size_t rinds_elems, const int *__restrict__ zind,
+    int numz, int nb, float powcut, int stage, const int64_t *__restrict__ blk_col0,
+    DevHit *__restrict__ hits, unsigned int *__restrict__ count, unsigned int max_hits)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int zi = blockIdx.y, b = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    float p = 0.f;
+    if (j < USELEN) {
+        const size_t cell = ((size_t) zi * nb + b) * USELEN + j;
+        p = fund[cell];
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const int src = rinds[s * rinds_elems + (size_t) b * USELEN + j];
+            p += sub[s * sub_elems + ((size_t) zind[s * numz + zi] * nb + b) * sub_stride + src];
+        }
+        fund[cell] = p;
+    }
+    const bool hit = j < USELEN && p > powcut;
+    const unsigned long long mask = __ballot(hit);
+    if (mask) {
+        unsigned int base = 0;
+        const int leader = __ffsll((long long) mask) - 1;
+        if (lane == leader)
+            base = atomicAdd(count, (unsigned int) __popcll(mask));
+        base = __shfl(base, leader);
+        if (hit) {
+            const unsigned int pos = base + (unsigned int) __popcll(mask & ((1ull << lane) - 1ull));
+            if (pos < max_hits)
+                hits[pos] = DevHit{p, ((uint32_t) stage << 16) | (uint32_t) zi, blk_col0[b] + j};
+        }
+    }
+}
+
 // Threshold scan of nb blocks laid out [z][block][column].
 __global__ __launch_bounds__(256) void k_batch_threshold(const float *__restrict__ pow,
                                                         float powcut, int stage,
