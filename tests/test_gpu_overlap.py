@@ -114,3 +114,21 @@ def test_misuse_is_refused(gpu):
     # drained: everything works again
     h3, k3, o3 = _plain(gpu, setup, specs[3])
     assert len(h3) > 0
+
+
+def test_reload_keeps_the_spectrum_of_a_queued_optimisation(gpu):
+    specs = _spectra()
+    setup = gpu.configure(N // 2, N, DT, ZMAX, NH, fhi=4000.0)
+    h0, k0, o0 = _plain(gpu, setup, specs[0])
+    gpu.load_fft(specs[0])
+    gpu.run_launch()
+    gpu.run_launch()                                        # the same spectrum twice
+    gpu.run_collect()
+    n = gpu.optimize_launch(k0)                             # beside the second search
+    gpu.run_collect()
+    gpu.load_fft(specs[1])                                  # nothing in flight: must still not land on specs[0]
+    gpu.load_fft(specs[2])
+    assert gpu.optimize_collect(n).tobytes() == o0.tobytes()
+    h2, k2, o2 = _plain(gpu, setup, specs[2])
+    hits = gpu.run()
+    assert np.array_equal(hits, h2)
