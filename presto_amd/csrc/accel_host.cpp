@@ -256,7 +256,10 @@ int replay(const accelgpu_setup *s, const accelgpu_hit *hits, int64_t n_hits,
 {
     const double CLOSEST = 15.0;
     std::vector<Entry> list;
+    std::vector<double> pmax; // running maximum of list[..].r, same length as list
     list.reserve(1024);
+    pmax.reserve(1024);
+    const bool linear_walk = std::getenv("ACCELGPU_REPLAY_LINEAR") != nullptr; // A/B against the plain walk
     const double zlo = s->zlo;
     for (int64_t i = 0; i < n_hits; i++)
         if (hits[i].stage < 0 || hits[i].stage >= s->numharmstages) {
@@ -300,40 +303,61 @@ int replay(const accelgpu_setup *s, const accelgpu_hit *hits, int64_t n_hits,
         int added = 0;
         if (list.empty()) {
             list.push_back(e);
+            pmax.push_back(rr);
             added = 1;
         } else {
-            size_t cur = 0;
             const size_t last = list.size() - 1;
-            while (cur < last && list[cur].r < rr)
-                cur++;
+            // first entry with r >= rr, or the last one: the reference's walk from the head.
+            // pmax[i] = max r of entries 0..i never decreases, and its first value >= rr sits
+            // at the first entry >= rr, so the walk is a binary search.
+            size_t cur;
+            if (linear_walk) {
+                cur = 0;
+                while (cur < last && list[cur].r < rr)
+                    cur++;
+            } else {
+                cur = (size_t) (std::lower_bound(pmax.begin(), pmax.begin() + (std::ptrdiff_t) last, rr) -
+                                pmax.begin());
+            }
             const bool has_prev = cur > 0;
             const double next_diff = std::fabs(rr - list[cur].r);
             const double prev_diff = has_prev ? std::fabs(rr - list[cur - 1].r) : CLOSEST + 1.0;
+            size_t dirty = list.size(); // first position whose prefix maximum may have changed
             if (prev_diff < CLOSEST) {
                 if (list[cur - 1].sigma < sig) {
                     list[cur - 1] = e;
+                    dirty = cur - 1;
                     added = 1;
                 }
                 if (next_diff < CLOSEST && list[cur].sigma < sig) {
                     if (added) {
-                        list.erase(list.begin() + cur);
+                        list.erase(list.begin() + (std::ptrdiff_t) cur);
+                        pmax.pop_back();
                     } else {
                         list[cur] = e;
+                        dirty = cur;
                         added = 1;
                     }
                 }
             } else if (next_diff < CLOSEST) {
                 if (list[cur].sigma < sig) {
                     list[cur] = e;
+                    dirty = cur;
                     added = 1;
                 }
             } else {
                 added = 1;
-                if (cur == last && list[cur].r < rr - CLOSEST)
+                if (cur == last && list[cur].r < rr - CLOSEST) {
                     list.push_back(e);
-                else
-                    list.insert(list.begin() + cur, e); // before cur (also the new-head case)
+                    dirty = list.size() - 1;
+                } else {
+                    list.insert(list.begin() + (std::ptrdiff_t) cur, e); // before cur (also the new-head case)
+                    dirty = cur;
+                }
+                pmax.push_back(0.0);
             }
+            for (size_t k = dirty; k < list.size(); k++)
+                pmax[k] = k == 0 ? list[0].r : std::max(pmax[k - 1], list[k].r);
         }
         if (added_out)
             added_out[i] = added;
