@@ -21,14 +21,19 @@ namespace afft {
 
 typedef float c32 __attribute__((ext_vector_type(2)));
 
+// Complex products written on whole vectors: one packed multiply and one packed fused
+// multiply-add, the swap of halves and the sign left to operand selects and modifiers.
 __device__ __forceinline__ c32 cmul(c32 a, c32 b)
 {
-    return c32{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+    const c32 t = a.xx * b;
+    return __builtin_elementwise_fma(a.yy, c32{-b.y, b.x}, t);
 }
+__device__ __forceinline__ c32 cmul_s(c32 a, c32 b) { return cmul(a, b); }
 // a * conj(b)
 __device__ __forceinline__ c32 cmul_conj(c32 a, c32 b)
 {
-    return c32{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y};
+    const c32 t = a * b.xx;
+    return __builtin_elementwise_fma(a.yx, c32{b.y, -b.y}, t);
 }
 template <int DIR> __device__ __forceinline__ c32 mul_i(c32 a)
 {
@@ -101,10 +106,21 @@ template <int N, int DIR, int SER = 0> struct Dft {
         if constexpr (K == 0) {
             t = o[0];
         } else if constexpr (4 * K == N) {
-            t = mul_i<DIR>(o[K]);
+            // e +- i*o (DIR > 0) or e -+ i*o in one packed add each: the swap of o's halves
+            // and the sign ride on the operand selects instead of on register moves (the
+            // compiler does not form these from vector code; it does for cmul above)
+            c32 p, m;
+            const c32 a = e[K], b = o[K];
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(p) : "v"(a), "v"(b));
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(m) : "v"(a), "v"(b));
+            v[K] = DIR > 0 ? p : m;
+            v[K + N / 2] = DIR > 0 ? m : p;
+            if constexpr (K + 1 < N / 2)
+                combine<K + 1>(v, e, o);
+            return;
         } else {
             constexpr int J = K * (32 / N);
-            t = cmul(o[K], c32{kCos32[J], DIR * kSin32[J]});
+            t = cmul_s(o[K], c32{kCos32[J], DIR * kSin32[J]});
         }
         v[K] = e[K] + t;
         v[K + N / 2] = e[K] - t;

@@ -1,6 +1,6 @@
 """Times plane generation (block prep + correlate) alone on a cfg2-sized spectrum."""
 import sys, os, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import presto_amd as pa
 from presto_amd import synth
 numbins = 1 << (int(sys.argv[2]) if len(sys.argv) > 2 else 22)

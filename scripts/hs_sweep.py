@@ -1,6 +1,6 @@
 """Times the harmonic-sum kernel alone on a cfg2-sized plane (env knobs select variants)."""
 import sys, os, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import presto_amd as pa
 from presto_amd import synth
 numbins = 1 << 22
