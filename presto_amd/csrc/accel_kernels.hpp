@@ -358,8 +358,12 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate(
         // The tables are loop-invariant; left alone the compiler hoists every
         // load of them out of the block loop and runs out of registers.  Launder
         // the pointers so each block re-reads them (L1/L2 hits).
-        const c32 *tw1_l = tw1, *tw2_l = tw2, *krow_l = krow;
-        asm volatile("" : "+s"(tw1_l), "+s"(tw2_l), "+s"(krow_l));
+        const c32 *tw1_0 = tw1, *tw2_0 = tw2, *krow_0 = krow;
+        asm volatile("" : "+s"(tw1_0), "+s"(tw2_0), "+s"(krow_0));
+        // the laundering hides that these point to global memory: say so again, or the
+        // loads become flat loads, which also count against the LDS wait counter
+        typedef const c32 __attribute__((address_space(1))) *gptr;
+        const gptr tw1_l = (gptr) tw1_0, tw2_l = (gptr) tw2_0, krow_l = (gptr) krow_0;
         const c32 *D = blockfft + (size_t) blk * NF;
         c32 dreg[H];
 #pragma unroll
@@ -447,6 +451,10 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
         const int ncols = blk_ncols[blk];
         // launder the pointer: the loads must stay inside the loop (hoisted, they
         // would pin another 2*H registers per block across the whole transform)
+        // (The laundering also hides that krow points to global memory, so its loads are
+        // flat loads.  Measured: typed as global again they are placed one by one right
+        // before their use, each with a full wait, and the kernel takes 5.6 instead of
+        // 4.2 ms; the table-twiddle kernel above gains 13 % from the same typing.)
         const c32 *D = blockfft + (size_t) blk * NF;
         const c32 *krow_l = krow;
         asm volatile("" : "+s"(D), "+s"(krow_l));

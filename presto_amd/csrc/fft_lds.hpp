@@ -285,9 +285,8 @@ __device__ __forceinline__ void fft3x(c32 *lds, Load load, Tw1 tw1, Tw2 tw2, Mid
 
 // Table form: tw1 is the [R1][M1] table of exp(DIR*2*pi*i*b*n1/N), tw2 the
 // [R2][R3] table of exp(DIR*2*pi*i*e*d/M1).
-template <class P, int DIR, class Load, class Store>
-__device__ __forceinline__ void fft3(c32 *lds, const c32 *__restrict__ tw1,
-                                     const c32 *__restrict__ tw2, Load load, Store store)
+template <class P, int DIR, class Tab, class Load, class Store>
+__device__ __forceinline__ void fft3(c32 *lds, Tab tw1, Tab tw2, Load load, Store store)
 {
     fft3x<P, DIR>(
         lds, load,
