@@ -7,9 +7,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu > $OUT/bench_under_trace.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu > $OUT/pmc_fetch.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu > $OUT/pmc_write.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $R/bench.py --steps 20 --warmup 3 --timed-only > $OUT/bench_under_trace.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python3 $R/bench.py --steps 3 --warmup 1 --timed-only > $OUT/pmc_fetch.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python3 $R/bench.py --steps 3 --warmup 1 --timed-only > $OUT/pmc_write.log 2>&1
 cd $R
 python3 scripts/pmc_sum.py $OUT/pmc_fetch/f_counter_collection.csv accelk > $OUT/pmc_summary.txt
 python3 scripts/pmc_sum.py $OUT/pmc_write/w_counter_collection.csv accelk >> $OUT/pmc_summary.txt
