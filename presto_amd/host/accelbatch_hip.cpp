@@ -1,0 +1,372 @@
+// accelbatch_hip -- many DM-trial files through one GPU context, pipelined.
+//
+//   accelbatch_hip [-zmax Z] [-numharm H] [-sigma S] [-flo F] [-fhi F] [-locpow]
+//                  [-noharmpolish] [-noharmremove] [-zaplist file [-baryv v]]
+//                  [-rednoise] [-device D] [-quiet]  file1.fft file2.fft ... (.dat/.sdat too)
+//
+// Per file this is what accelsearch_hip does (the reference's accelsearch, one process
+// per DM trial in the survey scripts, bin/GBNCC_search.py:360-394): search, work file,
+// candidate trimming, optimisation, <root>_ACCEL_<zmax> and .cand.  Here the files move
+// through three stages at once: a reader thread has the next file in memory, the GPU
+// searches the current one (its upload and preparation ran beside the previous search),
+// and the host finishes the previous one -- list replay, work file, trimming, and the
+// optimisation of its candidates on the device beside the running search.  The zapping
+// and red-noise steps of the survey scripts (zapbirds -zap, rednoise, :367-377) run on
+// the spectrum in device memory instead of as file-to-file passes: -zaplist applies to
+// every input here (accelsearch itself zaps only a time series), -rednoise to .fft input
+// (a time series is de-reddened as accelsearch does).
+// In-memory search only: every trial's plane must fit the device.
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "accelgpu.h"
+
+namespace {
+
+void die(const char *what)
+{
+    fprintf(stderr, "\n%s: %s\n\n", what, accelgpu_last_error());
+    exit(1);
+}
+
+// "<key text>  =  <value>" lines of a .inf file (reference src/ioinf.c:121-175)
+bool inf_value(const std::string &text, const char *key, double *out)
+{
+    const size_t at = text.find(key);
+    if (at == std::string::npos)
+        return false;
+    const size_t eq = text.find('=', at), nl = text.find('\n', at);
+    if (eq == std::string::npos || (nl != std::string::npos && eq > nl))
+        return false;
+    *out = atof(text.c_str() + eq + 1);
+    return true;
+}
+
+struct Options {
+    int zmax = 200, numharm = 8, device = 0, norm_type = 0;
+    double sigma = 2.0, flo = 1.0, fhi = 10000.0, baryv = 0.0;
+    bool polish = true, harmremove = true, rednoise = false, quiet = false;
+    std::string zaplist;
+};
+
+struct Trial {
+    std::string path, root, inftext, error;
+    bool dat_input = false;
+    double N = 0, dt = 0;
+    int64_t numbins = 0;
+    std::vector<float> data;     // packed spectrum (2*numbins floats) or the time series
+    accelgpu_setup setup{};
+    int64_t nopt = 0;            // candidates handed to the optimisation
+    std::vector<accelgpu_cand> kept;
+};
+
+// Host side of the input; no GPU call, runs on the reader thread.
+std::unique_ptr<Trial> read_trial(const std::string &path)
+{
+    std::unique_ptr<Trial> t(new Trial);
+    t->path = path;
+    auto ends_with = [&](const char *suf) {
+        const size_t n = strlen(suf);
+        return path.size() > n && path.compare(path.size() - n, n, suf) == 0;
+    };
+    const bool is_sdat = ends_with(".sdat"), is_dat = !is_sdat && ends_with(".dat");
+    t->dat_input = is_dat || is_sdat;
+    if (!t->dat_input && !ends_with(".fft")) {
+        t->error = "Input file ('" + path + "') must be an '.fft' or '.[s]dat' file!";
+        return t;
+    }
+    t->root = path.substr(0, path.size() - (is_sdat ? 5 : 4));
+    if (FILE *fi = fopen((t->root + ".inf").c_str(), "rb")) {
+        char buf[4096];
+        size_t got;
+        while ((got = fread(buf, 1, sizeof(buf), fi)) > 0)
+            t->inftext.append(buf, got);
+        fclose(fi);
+    }
+    if (!inf_value(t->inftext, "Number of bins in the time series", &t->N) ||
+        !inf_value(t->inftext, "Width of each time series bin", &t->dt)) {
+        t->error = "Cannot read N and dt from '" + t->root + ".inf'";
+        return t;
+    }
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) {
+        t->error = "Cannot open '" + path + "'";
+        return t;
+    }
+    fseek(f, 0, SEEK_END);
+    const long long bytes = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    bool ok = true;
+    if (is_sdat) {
+        const size_t n = (size_t) (bytes / 2);
+        std::vector<short> tmp(n);
+        ok = fread(tmp.data(), 2, n, f) == n;
+        t->data.resize(n);
+        for (size_t i = 0; i < n; i++)
+            t->data[i] = (float) tmp[i];
+        t->numbins = (int64_t) (n / 2);
+    } else {
+        const size_t n = (size_t) (bytes / 4);
+        t->data.resize(n);
+        ok = fread(t->data.data(), 4, n, f) == n;
+        t->numbins = (int64_t) (n / 2);
+    }
+    fclose(f);
+    if (!ok)
+        t->error = "Short read on '" + path + "'";
+    else if (t->dat_input && t->data.size() > 67108864)
+        t->error = "The input time series '" + path + "' is too large.  Use 'realfft' first.";
+    return t;
+}
+
+// Bounded hand-over from the reader thread.
+class Mailbox {
+  public:
+    void put(std::unique_ptr<Trial> t)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        room_.wait(lk, [&] { return q_.size() < 2; });
+        q_.push_back(std::move(t));
+        some_.notify_one();
+    }
+    std::unique_ptr<Trial> get() // nullptr: no more files
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        some_.wait(lk, [&] { return !q_.empty(); });
+        std::unique_ptr<Trial> t = std::move(q_.front());
+        q_.pop_front();
+        room_.notify_one();
+        return t;
+    }
+
+  private:
+    std::mutex m_;
+    std::condition_variable some_, room_;
+    std::deque<std::unique_ptr<Trial>> q_;
+};
+
+struct Geometry {
+    int64_t numbins = -1;
+    double N = 0, dt = 0;
+    bool same(const Trial &t) const { return numbins == t.numbins && N == t.N && dt == t.dt; }
+};
+
+struct Birds {
+    double T = -1;
+    std::vector<double> lo, hi;
+    int32_t use = 0;
+};
+
+// Upload, prepare and launch one trial (beside a search still in flight).
+void stage_trial(accelgpu_ctx *gpu, Trial &t, const Options &o, Geometry &geo, accelgpu_setup &su, Birds &birds)
+{
+    if (!geo.same(t)) { // the caller has drained the GPU
+        if (accelgpu_plan(t.numbins, (long long) t.N, t.dt, o.zmax, o.numharm, o.sigma, o.flo, o.fhi, 0, &su))
+            die("accelgpu_plan");
+        if (accelgpu_build_kernels(gpu, su.zmax)) die("accelgpu_build_kernels");
+        if (accelgpu_set_search(gpu, &su, o.norm_type, 0.f)) die("accelgpu_set_search");
+        geo.numbins = t.numbins;
+        geo.N = t.N;
+        geo.dt = t.dt;
+    }
+    t.setup = su;
+    if (t.dat_input) {
+        if (accelgpu_load_dat(gpu, t.data.data(), (int64_t) t.data.size(), 1)) die("accelgpu_load_dat");
+    } else if (accelgpu_load_fft(gpu, t.data.data(), t.numbins)) {
+        die("accelgpu_load_fft");
+    }
+    std::vector<float>().swap(t.data);
+    if (!o.zaplist.empty()) {
+        if (birds.T != su.T) { // the list in bins of this observation length, cut at the Nyquist bin
+            int32_t nb = 0;
+            birds.lo.assign(1, 0.0);
+            birds.hi.assign(1, 0.0);
+            int rc = accelgpu_read_birds(o.zaplist.c_str(), su.T, o.baryv, birds.lo.data(), birds.hi.data(), 0, &nb);
+            if (rc == ACCELGPU_ERR_OVERFLOW) {
+                birds.lo.resize((size_t) nb);
+                birds.hi.resize((size_t) nb);
+                rc = accelgpu_read_birds(o.zaplist.c_str(), su.T, o.baryv, birds.lo.data(), birds.hi.data(), nb, &nb);
+            }
+            if (rc) die("accelgpu_read_birds");
+            const double hibin = (double) ((long long) t.N / 2);
+            birds.use = 0;
+            for (; birds.use < nb && birds.lo[(size_t) birds.use] < hibin; birds.use++)
+                if (birds.hi[(size_t) birds.use] >= hibin)
+                    birds.hi[(size_t) birds.use] = hibin - 1;
+            birds.T = su.T;
+        }
+        if (accelgpu_zapbirds(gpu, birds.lo.data(), birds.hi.data(), birds.use)) die("accelgpu_zapbirds");
+    }
+    if (o.rednoise && !t.dat_input)
+        if (accelgpu_rednoise(gpu, 6, 100, 6.0, su.T)) die("accelgpu_rednoise");
+    if (accelgpu_run_launch(gpu)) die("accelgpu_run_launch");
+}
+
+// Collect a launched trial: list replay, work file, trimming, optimisation queued.
+void collect_trial(accelgpu_ctx *gpu, Trial &t, const Options &o, std::vector<accelgpu_hit> &hits)
+{
+    const accelgpu_setup &su = t.setup;
+    int64_t nhits = 0;
+    int rc;
+    while ((rc = accelgpu_run_collect(gpu, hits.data(), (int64_t) hits.size(), &nhits)) == ACCELGPU_ERR_OVERFLOW &&
+           nhits > (int64_t) hits.size())
+        hits.resize((size_t) nhits + 1024);
+    if (rc) die("accelgpu_run_collect");
+    std::vector<accelgpu_cand> cands((size_t) nhits + 1);
+    std::vector<float> sig((size_t) nhits + 1);
+    std::vector<int32_t> added((size_t) nhits + 1);
+    int64_t ncands = 0;
+    if (accelgpu_replay_candidates(&su, hits.data(), nhits, cands.data(), (int64_t) cands.size(), &ncands, sig.data(),
+                                   added.data()))
+        die("accelgpu_replay_candidates");
+    if (!t.dat_input) { // the work file of the search (src/accel_utils.c:1290-1294)
+        const std::string work = t.root + "_ACCEL_" + std::to_string(su.zmax) + ".txtcand";
+        FILE *w = fopen(work.c_str(), "w");
+        if (!w) {
+            perror(work.c_str());
+            exit(1);
+        }
+        for (int64_t i = 0; i < nhits; i++)
+            if (added[(size_t) i]) {
+                const int nh = 1 << hits[(size_t) i].stage;
+                const double rr = hits[(size_t) i].rind * 0.5 / nh, zz = (su.zlo + hits[(size_t) i].zind * 2.0) / nh;
+                fprintf(w, "%-7.2f  %-7.4f  %-2d  %-14.4f  %-14.9f  %-10.4f\n", hits[(size_t) i].power,
+                        sig[(size_t) i], nh, rr, rr / su.T, zz);
+            }
+        fclose(w);
+    }
+    t.nopt = 0;
+    if (ncands > 0) {
+        int64_t kept = 0;
+        if (accelgpu_sort_and_eliminate(cands.data(), ncands, su.numharm > 1 && o.harmremove, &kept))
+            die("accelgpu_sort_and_eliminate");
+        t.kept.assign(cands.begin(), cands.begin() + kept);
+        if (accelgpu_optimize_launch(gpu, t.kept.data(), kept, o.polish ? 1 : 0)) die("accelgpu_optimize_launch");
+        t.nopt = kept;
+    }
+    if (!o.quiet)
+        printf("%s: %lld cells above threshold, %lld candidates, %lld kept\n", t.path.c_str(), (long long) nhits,
+               (long long) ncands, (long long) t.nopt);
+}
+
+// Wait for the optimisation and write the result files.
+void write_trial(accelgpu_ctx *gpu, Trial &t)
+{
+    if (t.nopt == 0)
+        return;
+    std::vector<accelgpu_optcand> opt((size_t) t.nopt);
+    if (accelgpu_optimize_collect(gpu, opt.data(), t.nopt)) die("accelgpu_optimize_collect");
+    const std::string accelnm = t.root + "_ACCEL_" + std::to_string(t.setup.zmax);
+    if (accelgpu_write_accel_files(&t.setup, opt.data(), t.nopt, 0.f, accelnm.c_str(), (accelnm + ".cand").c_str(),
+                                   t.inftext.c_str()))
+        die("accelgpu_write_accel_files");
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    Options o;
+    std::vector<std::string> files;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto need = [&](const char *flag) {
+            if (i + 1 >= argc) {
+                printf("\nMissing value for %s\n\n", flag);
+                exit(1);
+            }
+            return argv[++i];
+        };
+        if (a == "-zmax") o.zmax = atoi(need("-zmax"));
+        else if (a == "-numharm") o.numharm = atoi(need("-numharm"));
+        else if (a == "-sigma") o.sigma = atof(need("-sigma"));
+        else if (a == "-flo") o.flo = atof(need("-flo"));
+        else if (a == "-fhi") o.fhi = atof(need("-fhi"));
+        else if (a == "-device") o.device = atoi(need("-device"));
+        else if (a == "-zaplist") o.zaplist = need("-zaplist");
+        else if (a == "-baryv") o.baryv = atof(need("-baryv"));
+        else if (a == "-ncpus") (void) need("-ncpus");
+        else if (a == "-locpow") o.norm_type = 1;
+        else if (a == "-median") o.norm_type = 0;
+        else if (a == "-inmem" || a == "-otheropt") {}
+        else if (a == "-rednoise") o.rednoise = true;
+        else if (a == "-noharmpolish") o.polish = false;
+        else if (a == "-noharmremove") o.harmremove = false;
+        else if (a == "-quiet") o.quiet = true;
+        else if (a[0] == '-') {
+            printf("\nUnknown option '%s'\n\n", a.c_str());
+            return 1;
+        } else files.push_back(a);
+    }
+    if (files.empty()) {
+        printf("\nusage: accelbatch_hip [search flags] file1.fft file2.fft ...\n\n");
+        return 1;
+    }
+    if (o.zmax < 0 || o.zmax > 1200 || o.sigma < 1.0 || o.sigma > 30.0 || o.baryv < -0.1 || o.baryv > 0.1) {
+        printf("\n-zmax must be in 0..1200, -sigma in 1..30 and -baryv in -0.1..0.1\n\n");
+        return 1;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    accelgpu_ctx *gpu = nullptr;
+    if (accelgpu_create(&gpu, o.device)) die("accelgpu_create");
+
+    Mailbox box;
+    std::thread reader([&] {
+        for (const std::string &f : files)
+            box.put(read_trial(f));
+        box.put(nullptr);
+    });
+
+    Geometry geo;
+    accelgpu_setup su{};
+    Birds birds;
+    std::vector<accelgpu_hit> hits((size_t) 1 << 18);
+    std::unique_ptr<Trial> launched, optimising;
+    // One step for the trials behind the newest launch: the older optimisation's results
+    // out to the files, the collected search's candidates to the device.
+    auto advance = [&] {
+        if (optimising) {
+            write_trial(gpu, *optimising);
+            optimising.reset();
+        }
+        if (launched) {
+            collect_trial(gpu, *launched, o, hits);
+            optimising = std::move(launched);
+        }
+    };
+    size_t done = 0;
+    for (;;) {
+        std::unique_ptr<Trial> t = box.get();
+        if (!t)
+            break;
+        if (!t->error.empty()) {
+            fprintf(stderr, "\n%s\n\n", t->error.c_str());
+            reader.detach();
+            return 1;
+        }
+        if (launched && !geo.same(*t))
+            advance(); // a new geometry rebuilds the plane: drain first
+        std::unique_ptr<Trial> prev = std::move(launched);
+        stage_trial(gpu, *t, o, geo, su, birds); // queued behind prev's search on the GPU
+        launched = std::move(prev);
+        advance();                               // host work and optimisation overlap t's search
+        launched = std::move(t);
+        done++;
+    }
+    advance();
+    advance();
+    reader.join();
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("\n%zu files in %.3f sec (%.1f files/s)\n\n", done, secs, done / secs);
+    accelgpu_destroy(gpu);
+    return 0;
+}

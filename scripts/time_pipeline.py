@@ -32,3 +32,10 @@ for rep in range(2):
         rep, nfiles, dt, nfiles / dt, " ".join("%.1f" % (1e3 * s) for s in secs), len(cl)))
     print("    ms per file: " + "  ".join("%s %.2f" % (k, 1e3 * v / nfiles) for k, v in pipeline.TIMES.items()))
     pipeline.TIMES.clear()
+
+# the native program on the same files
+import subprocess
+exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "presto_amd", "host", "accelbatch_hip")
+for rep in range(2):
+    out = subprocess.check_output([exe, "-zmax", "200", "-numharm", "16", "-fhi", "1e9", "-quiet"] + sorted(files)).decode()
+    print("accelbatch_hip pass %d: %s" % (rep, out.strip().splitlines()[-1]))

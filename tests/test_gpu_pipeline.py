@@ -59,3 +59,39 @@ def test_pipeline_finds_the_pulsar_across_dm_trials(tmp_path):
     cl2 = pipeline.sift(cl2, ["0.00", "10.00", "20.00", "30.00"], 2, 2.0, verbosity=0)
     assert [(c.filename, c.candnum) for c in cl2] == [(c.filename, c.candnum) for c in cl]
     assert [c.sigma for c in cl2] == [c.sigma for c in cl]
+
+
+def test_native_batch_program_equals_one_run_per_file(tmp_path):
+    """accelbatch_hip (many files through one context, pipelined) writes byte for byte the
+    ACCEL, .cand and .txtcand files that accelsearch_hip writes one file at a time,
+    including a time-series input and a change of series length in mid-batch."""
+    import shutil
+    import subprocess
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    one = os.path.join(root_dir, "presto_amd", "host", "accelsearch_hip")
+    many = os.path.join(root_dir, "presto_amd", "host", "accelbatch_hip")
+    a, b = tmp_path / "single", tmp_path / "batch"
+    a.mkdir()
+    b.mkdir()
+    names = []
+    for k, (N, ext) in enumerate([(1 << 19, ".fft"), (1 << 19, ".fft"), (1 << 19, ".dat"), (1 << 18, ".fft"), (1 << 18, ".fft")]):
+        dt = 2.5e-4
+        puls = [dict(f=77.7 + k, z=-11.0 + 4 * k, amp=0.3, duty=0.05), dict(f=201.0, z=3.0, amp=0.2, duty=0.1)]
+        root = str(a / ("t%d_DM%.2f" % (k, 5.0 * k)))
+        if ext == ".dat":
+            synth.pulsar_series(N, dt, puls, seed=60 + k).astype(np.float32).tofile(root + ".dat")
+            open(root + ".inf", "w").write(synth.inf_text(os.path.basename(root), N, dt))
+        else:
+            synth.write_fft(root, synth.make_fft(N, dt, puls, seed=60 + k), N, dt)
+        names.append(os.path.basename(root) + ext)
+    for n in os.listdir(str(a)):
+        shutil.copy(str(a / n), str(b / n))
+    flags = ["-zmax", "20", "-numharm", "8", "-sigma", "3.0", "-fhi", "1900"]
+    for n in names:
+        subprocess.check_output([one] + flags + [str(a / n)], timeout=170)
+    out = subprocess.check_output([many] + flags + [str(b / n) for n in names], timeout=170).decode()
+    assert "5 files in" in out
+    made = sorted(n for n in os.listdir(str(a)) if "_ACCEL_" in n)
+    assert len(made) == 3 * 4 + 2 and made == sorted(n for n in os.listdir(str(b)) if "_ACCEL_" in n)
+    for n in made:
+        assert open(str(a / n), "rb").read() == open(str(b / n), "rb").read(), n
