@@ -125,7 +125,8 @@ def test_photon_normalisation(gpu, oracle):
 
 
 @pytest.mark.parametrize("name,N,zmax,numharm", [("cfg1", 1 << 19, 0, 8), ("cfg2", 1 << 18, 200, 16),
-                                                 ("cfg2", 1 << 18, 40, 32)])
+                                                 ("cfg2", 1 << 18, 40, 32), ("cfg2", 1 << 18, 60, 4),
+                                                 ("cfg2", 1 << 18, 60, 2), ("cfg2", 1 << 18, 60, 1)])
 def test_harmonic_sum_and_threshold_bit_exact(gpu, oracle, name, N, zmax, numharm):
     """Both sides sum and threshold the SAME plane (the GPU's): every hit must
     match bit for bit, in the same order, and so must the candidate lists."""
