@@ -318,6 +318,43 @@ __global__ __launch_bounds__(P::NT) void k_block_prep(
 }
 
 // ---------------------------------------------------------------------------
+// Stores of one transform's kept outputs into a plane row, through a buffer
+// descriptor over the block's columns [out, out + ncols): the hardware range check
+// drops the outputs that fall before the first or after the last column, so a store
+// is one instruction with a 32-bit byte offset and no compare, mask or 64-bit address.
+// A thread's outputs are n = t + c, c a compile-time multiple of NT; its byte offset
+// is 4*(n - shift).  Outputs with c < 2048 can lie before the block (shift <= 2048 is
+// checked on the host): each of those has its own offset register, so a negative offset
+// reaches the range check as a large unsigned number; the others share one register per
+// 4096 bytes (never negative) and carry the rest as the instruction's immediate.
+// ---------------------------------------------------------------------------
+template <class P> struct PlaneStore {
+    static constexpr int NEAR = (P::N < 2048 ? P::N : 2048) / P::NT, NG = P::N >= 1024 ? P::N / 1024 : 1;
+    int vnear[NEAR], vgrp[NG];
+    __device__ __forceinline__ PlaneStore(int t, int shift)
+    {
+        const int voff = (t - shift) * 4;
+#pragma unroll
+        for (int i = 0; i < NEAR; i++) {
+            vnear[i] = voff + 4 * P::NT * i;
+            asm("" : "+v"(vnear[i])); // opaque: the sum must not be split into base + immediate again
+        }
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            vgrp[g] = voff + 4096 * g;
+            asm("" : "+v"(vgrp[g]));
+        }
+    }
+    __device__ __forceinline__ void operator()(__amdgpu_buffer_rsrc_t rsrc, int c, float p) const
+    {
+        if (c < 2048)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(p), rsrc, vnear[c / P::NT], 0, 0);
+        else
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(p), rsrc, vgrp[c / 1024] + 4 * (c % 1024), 0, 0);
+    }
+};
+
+// ---------------------------------------------------------------------------
 // Correlation: one workgroup per (template z, chunk of blocks).  The template's
 // spectrum stays in registers for the whole chunk.  For each block:
 //   X[k] = D[k mod N/2] * conj(K_z[k]);  x = IFFT_N(X) (unnormalised);
@@ -353,6 +390,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate(
     const float norm = 1.0f / ((float) P::N * (float) P::N);
     float *prow = plane + (size_t) z * (size_t) rlen;
     const int shift = 2 * halfwidth;
+    const PlaneStore<P> put(t, shift);
 
     for (int blk = b0; blk < b1; blk++) {
         // The tables are loop-invariant; left alone the compiler hoists every
@@ -371,6 +409,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate(
             dreg[a] = D[P::M1 * a + t];
         float *out = prow + blk_col[blk];
         const int ncols = blk_ncols[blk];
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, ncols * 4, 0x00020000);
         afft::fft3<P, +1>(
             lds, tw1_l, tw2_l,
             [&](int, int a, int) {
@@ -379,11 +418,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate(
                 else
                     return afft::cmul_conj(dreg[a % H], krow_l[P::M1 * a + t]);
             },
-            [&](int n, c32 v) {
-                const int j = n - shift;
-                if (j >= 0 && j < ncols)
-                    out[j] = (v.x * v.x + v.y * v.y) * norm;
-            });
+            [&](int n, c32 v) { put(rsrc, n - t, (v.x * v.x + v.y * v.y) * norm); });
         __syncthreads(); // pass-3 reads done before the next block's pass-1 writes
     }
 }
@@ -445,10 +480,12 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
     const float norm = 1.0f / ((float) P::N * (float) P::N);
     float *prow = plane + (size_t) z * (size_t) rlen;
     const int shift = 2 * halfwidth;
+    const PlaneStore<P> put(t, shift);
 
     for (int blk = b0; blk < b1; blk++) {
         float *out = prow + blk_col[blk];
         const int ncols = blk_ncols[blk];
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, ncols * 4, 0x00020000);
         // launder the pointer: the loads must stay inside the loop (hoisted, they
         // would pin another 2*H registers per block across the whole transform)
         // (The laundering also hides that krow points to global memory, so its loads are
@@ -474,11 +511,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
             },
             [&](int, int, c32 *v) { afft::apply_twiddles_2level<P::R1>(v, w1); },
             [&](int, int, c32 *v) { afft::apply_twiddles_2level<P::R2>(v, w2); }, [] {},
-            [&](int n, c32 v) {
-                const int j = n - shift;
-                if (j >= 0 && j < ncols)
-                    out[j] = (v.x * v.x + v.y * v.y) * norm;
-            });
+            [&](int n, c32 v) { put(rsrc, n - t, (v.x * v.x + v.y * v.y) * norm); });
         __syncthreads();
     }
 }
