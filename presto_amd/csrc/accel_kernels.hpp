@@ -481,6 +481,13 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
     float *prow = plane + (size_t) z * (size_t) rlen;
     const int shift = 2 * halfwidth;
     const PlaneStore<P> put(t, shift);
+    c32 dreg[H];
+    {
+        const c32 *D = blockfft + (size_t) b0 * NF;
+#pragma unroll
+        for (int a = 0; a < H; a++)
+            dreg[a] = D[P::M1 * a + t];
+    }
 
     for (int blk = b0; blk < b1; blk++) {
         float *out = prow + blk_col[blk];
@@ -492,15 +499,10 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
         // flat loads.  Measured: typed as global again they are placed one by one right
         // before their use, each with a full wait, and the kernel takes 5.6 instead of
         // 4.2 ms; the table-twiddle kernel above gains 13 % from the same typing.)
-        const c32 *D = blockfft + (size_t) blk * NF;
         const c32 *krow_l = krow;
-        asm volatile("" : "+s"(D), "+s"(krow_l));
+        asm volatile("" : "+s"(krow_l));
         afft::launder(w1);
         afft::launder(w2);
-        c32 dreg[H];
-#pragma unroll
-        for (int a = 0; a < H; a++)
-            dreg[a] = D[P::M1 * a + t];
         afft::fft3x<P, +1, SER>(
             lds,
             [&](int, int a, int) {
@@ -510,7 +512,17 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
                     return afft::cmul_conj(dreg[a % H], krow_l[P::M1 * a + t]);
             },
             [&](int, int, c32 *v) { afft::apply_twiddles_2level<P::R1>(v, w1); },
-            [&](int, int, c32 *v) { afft::apply_twiddles_2level<P::R2>(v, w2); }, [] {},
+            [&](int, int, c32 *v) { afft::apply_twiddles_2level<P::R2>(v, w2); },
+            [&] {
+                // the block spectrum is used up by pass 1: fetch the next block's into the
+                // same registers now, so that it arrives during passes 2 and 3
+                if (blk + 1 < b1) {
+                    const c32 *D = blockfft + (size_t) (blk + 1) * NF;
+#pragma unroll
+                    for (int a = 0; a < H; a++)
+                        dreg[a] = D[P::M1 * a + t];
+                }
+            },
             [&](int n, c32 v) { put(rsrc, n - t, (v.x * v.x + v.y * v.y) * norm); });
         __syncthreads();
     }
