@@ -345,6 +345,15 @@ template <class P> struct PlaneStore {
             asm("" : "+v"(vgrp[g]));
         }
     }
+    // Called once per block: the registers become opaque again, so the constant parts
+    // added below stay instruction immediates instead of being hoisted out of the block
+    // loop into one register per output.
+    __device__ __forceinline__ void refresh()
+    {
+#pragma unroll
+        for (int g = 0; g < NG; g++)
+            asm volatile("" : "+v"(vgrp[g]));
+    }
     __device__ __forceinline__ void operator()(__amdgpu_buffer_rsrc_t rsrc, int c, float p) const
     {
         if (c < 2048)
@@ -390,7 +399,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate(
     const float norm = 1.0f / ((float) P::N * (float) P::N);
     float *prow = plane + (size_t) z * (size_t) rlen;
     const int shift = 2 * halfwidth;
-    const PlaneStore<P> put(t, shift);
+    PlaneStore<P> put(t, shift);
 
     for (int blk = b0; blk < b1; blk++) {
         // The tables are loop-invariant; left alone the compiler hoists every
@@ -410,6 +419,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate(
         float *out = prow + blk_col[blk];
         const int ncols = blk_ncols[blk];
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, ncols * 4, 0x00020000);
+        put.refresh();
         afft::fft3<P, +1>(
             lds, tw1_l, tw2_l,
             [&](int, int a, int) {
@@ -480,7 +490,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
     const float norm = 1.0f / ((float) P::N * (float) P::N);
     float *prow = plane + (size_t) z * (size_t) rlen;
     const int shift = 2 * halfwidth;
-    const PlaneStore<P> put(t, shift);
+    PlaneStore<P> put(t, shift);
     c32 dreg[H];
     {
         const c32 *D = blockfft + (size_t) b0 * NF;
@@ -493,23 +503,36 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
         float *out = prow + blk_col[blk];
         const int ncols = blk_ncols[blk];
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, ncols * 4, 0x00020000);
+        put.refresh();
         // launder the pointer: the loads must stay inside the loop (hoisted, they
-        // would pin another 2*H registers per block across the whole transform)
-        // (The laundering also hides that krow points to global memory, so its loads are
-        // flat loads.  Measured: typed as global again they are placed one by one right
-        // before their use, each with a full wait, and the kernel takes 5.6 instead of
-        // 4.2 ms; the table-twiddle kernel above gains 13 % from the same typing.)
+        // would pin another 2*R1 registers across the whole transform)
         const c32 *krow_l = krow;
         asm volatile("" : "+s"(krow_l));
         afft::launder(w1);
         afft::launder(w2);
+        // The template's spectrum: all loads issued before the first product (buffer
+        // loads with the row offset in the scalar operand: no address arithmetic); the
+        // products start as the values arrive, in order.  (Typed as plain global loads the
+        // compiler places them one by one right before their use, each with a full wait:
+        // 5.6 ms against 3.3 ms.)
+        c32 kv[KEEPK ? 1 : P::R1];
+        if constexpr (!KEEPK) {
+            const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void *) krow_l, 0, P::N * 8, 0x00020000);
+#pragma unroll
+            for (int a = 0; a < P::R1; a++) {
+                typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+                const u2 r = __builtin_amdgcn_raw_buffer_load_b64(krs, t * 8, P::M1 * 8 * a, 0);
+                kv[a] = c32{__uint_as_float(r.x), __uint_as_float(r.y)};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         afft::fft3x<P, +1, SER>(
             lds,
             [&](int, int a, int) {
                 if constexpr (KEEPK)
                     return afft::cmul_conj(dreg[a % H], kreg[a]);
                 else
-                    return afft::cmul_conj(dreg[a % H], krow_l[P::M1 * a + t]);
+                    return afft::cmul_conj(dreg[a % H], kv[a]);
             },
             [&](int, int, c32 *v) { afft::apply_twiddles_2level<P::R1>(v, w1); },
             [&](int, int, c32 *v) { afft::apply_twiddles_2level<P::R2>(v, w2); },
