@@ -155,6 +155,7 @@ void orc_rz_interp(const orc_cf32 *data, long numdata, double r, double z, int k
 double orc_get_localpower3d(const orc_cf32 *data, long numdata, double r, double z);
 void orc_get_derivs3d(const orc_cf32 *data, long numdata, double r, double z, double localpower,
                       orc_rderivs *res);
+void orc_amoeba(double p[3][2], double *y, double ftol, double (*funk)(double *), int *nfunk);
 void orc_max_rz(const orc_cf32 *data, long numdata, int nharm, int r_offset, double rin, double zin,
                 int polish, double *rout, double *zout, orc_rderivs *derivs, double *power);
 void orc_optimize_cand(const orc_obs *obs, int polish, orc_optcand *c);

@@ -151,12 +151,17 @@ typedef struct {
     long numdata;
     int nharm, r_offset, khw, divide;
     float locpow[ORC_MAXHARM];
+    double (*plain)(double *); /* when set: the function minimised (orc_amoeba, used to pin the simplex) */
 } objective;
 
 /* power_call_rz_harmonics() / power_call_rz(), src/maximize_rz.c:11-20, 113-127 */
 static double objective_call(const objective *o, const double rz[2])
 {
     double total = 0.0;
+    if (o->plain) {
+        double x[2] = {rz[0], rz[1]};
+        return o->plain(x);
+    }
     orc_cf32 ans;
     for (int i = 1; i <= o->nharm; i++) {
         orc_rz_interp(o->data, o->numdata, (o->r_offset + rz[0]) * i - o->r_offset,
@@ -236,6 +241,16 @@ static void amoeba(double p[3][2], double *y, double ftol, const objective *o, i
     }
 }
 
+/* The simplex routine on a caller's function, with the reference's signature
+ * (src/amoeba.c:18-19): lets the tests run it beside the reference's own amoeba(). */
+void orc_amoeba(double p[3][2], double *y, double ftol, double (*funk)(double *), int *nfunk)
+{
+    objective o;
+    memset(&o, 0, sizeof o);
+    o.plain = funk;
+    amoeba(p, y, ftol, &o, nfunk);
+}
+
 /* max_rz_arr_harmonics(), src/maximize_rz.c:129-231 (all harmonics read the same
  * spectrum with the same offset, as optimize_accelcand() calls it).  With
  * polish == 0 and nharm == 1 this is max_rz_arr(), :22-92: the same two simplex
@@ -248,6 +263,7 @@ void orc_max_rz(const orc_cf32 *data, long numdata, int nharm, int r_offset, dou
     const double step = 0.4;
     int numeval, i;
 
+    o.plain = NULL;
     o.data = data;
     o.numdata = numdata;
     o.nharm = nharm;

@@ -1,9 +1,9 @@
 """Pins for the CPU oracle (no GPU).
 
-Pinned against the reference's own code (the four self-contained files built
+Pinned against the reference's own code (the five self-contained files built
 unmodified into oracle/_ref/libprestoref.so): Fresnel integrals, the quickselect
-median, and the chi^2 / normal routines behind power_for_sigma and
-candidate_sigma.  Pinned against mathematics: the z-response versus quadrature
+median, the chi^2 / normal routines behind power_for_sigma and candidate_sigma,
+and the downhill simplex of the candidate optimisation.  Pinned against mathematics: the z-response versus quadrature
 of its defining integral, the FFT versus a double-precision DFT.  Pinned against
 numbers recorded from a run of the reference program (tests/golden/setup_tables.json):
 half-widths, FFT lengths, block counts, numindep and powcut tables.
@@ -49,6 +49,58 @@ def test_median_matches_reference(oracle, ref):
             want = float(ref.median(b.ctypes.data_as(C.c_void_p), n))
             assert got == want
             assert got == float(np.sort(a)[(n - 1) // 2])
+
+
+def test_amoeba_matches_reference(oracle, ref):
+    """The oracle's simplex beside the reference's amoeba() (src/amoeba.c:18-75) on the
+    same functions, start simplexes and tolerances: the same vertices, values and
+    evaluation counts, bit for bit, including a run that stops at the evaluation cap."""
+    L = oracle.lib()
+    FN = C.CFUNCTYPE(C.c_double, C.POINTER(C.c_double))
+    P = (C.c_double * 2) * 3
+    Y = C.c_double * 3
+    for lib in (L.orc_amoeba, ref.amoeba):
+        lib.argtypes = [C.POINTER(C.c_double * 2), C.POINTER(C.c_double), C.c_double, FN, C.POINTER(C.c_int)]
+        lib.restype = None
+    rng = np.random.default_rng(11)
+    noise = rng.normal(0.0, 1e-9, 4096)
+
+    def bowl(x):
+        return (x[0] - 1.25) ** 2 + 3.0 * (x[1] + 0.5) ** 2 + 0.3 * (x[0] - 1.25) * (x[1] + 0.5)
+
+    def rosen(x):
+        return (1.0 - x[0]) ** 2 + 100.0 * (x[1] - x[0] * x[0]) ** 2
+
+    def peak(x):      # a negative power-like peak, as the optimisation minimises
+        return -50.0 * np.sinc(x[0] - 0.3) ** 2 * np.sinc(0.25 * (x[1] - 1.7)) ** 2
+
+    def rough(x):     # round-off-like noise: never reaches the tolerance, stops at the cap
+        k = int(abs(x[0] * 7919.0 + x[1] * 104729.0) * 1e6) % 4096
+        return bowl(x) + noise[k]
+
+    ncap = 0
+    for f in (bowl, rosen, peak, rough):
+        for ftol in (1e-7, 1e-10, 1e-15):
+            for rep in range(4):
+                x0, z0 = rng.uniform(-2, 2, 2)
+                step = (0.4, 0.01, 1.0, 0.4)[rep]
+                start = [[x0 - step, z0 - step], [x0 - step, z0 + step], [x0 + step, z0]]
+                outs = []
+                for lib in (L.orc_amoeba, ref.amoeba):
+                    calls = []
+
+                    def cb(px, f=f, calls=calls):
+                        v = float(f((px[0], px[1])))
+                        calls.append((px[0], px[1]))
+                        return v
+                    p = P(*[(C.c_double * 2)(*v) for v in start])
+                    y = Y(*[float(f(v)) for v in start])
+                    n = C.c_int(-1)
+                    lib(p, y, ftol, FN(cb), C.byref(n))
+                    outs.append(([list(r) for r in p], list(y), n.value, calls))
+                assert outs[0] == outs[1], (f.__name__, ftol, rep)
+                ncap += outs[0][2] >= 5000
+    assert ncap > 0          # the evaluation cap was exercised
 
 
 def _ref_power_for_sigma(ref, sigma, numsum, numtrials):
