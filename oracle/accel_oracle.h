@@ -13,6 +13,7 @@
  *   fresnl()  src/fresnl.c:175-216      <-> orc_fresnel()
  *   median()  src/median.c:12-69        <-> orc_median()
  *   cdfchi()/cdfnor() src/dcdflib.c     <-> orc_power_for_sigma()/orc_candidate_sigma()
+ *   amoeba()  src/amoeba.c:18-75        <-> orc_amoeba() (the simplex of the candidate optimisation)
  * The z-response is additionally pinned against direct quadrature of its
  * defining integral, and the FFT against a double-precision DFT.
  *
