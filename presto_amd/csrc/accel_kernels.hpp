@@ -509,7 +509,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
         const c32 *krow_l = krow;
         asm volatile("" : "+s"(krow_l));
         afft::launder(w1);
-        afft::launder(w2);
+        // w2 is not laundered: its nine products stay hoisted out of the block loop (18 more registers)
         // The template's spectrum: all loads issued before the first product (buffer
         // loads with the row offset in the scalar operand: no address arithmetic); the
         // products start as the values arrive, in order.  (Typed as plain global loads the
