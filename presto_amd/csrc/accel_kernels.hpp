@@ -312,9 +312,13 @@ __global__ __launch_bounds__(P::NT) void k_block_prep(
         }
     }
     __syncthreads();
+    // The spectrum is stored times 1/(2*P::N), one over the length of the correlation it
+    // feeds: a power of two, so every later product and sum is the unscaled one times that
+    // power exactly, and the correlate kernels' |x|^2 needs no 1/N^2 any more.
     c32 *out = blockfft + (size_t) blk * P::N;
+    constexpr float kScale = 1.0f / (2.0f * (float) P::N);
     afft::fft3<P, -1>(
-        lds, tw1, tw2, [&](int, int a, int) { return d[a]; }, [&](int n, c32 v) { out[n] = v; });
+        lds, tw1, tw2, [&](int, int a, int) { return d[a]; }, [&](int n, c32 v) { out[n] = v * kScale; });
 }
 
 // ---------------------------------------------------------------------------
@@ -368,6 +372,7 @@ template <class P> struct PlaneStore {
 // spectrum stays in registers for the whole chunk.  For each block:
 //   X[k] = D[k mod N/2] * conj(K_z[k]);  x = IFFT_N(X) (unnormalised);
 //   plane[z][col_b + j] = |x[j + 2*halfwidth]|^2 / N^2,  0 <= j < ncols_b
+// (the 1/N comes with D: k_block_prep stores the block spectra already scaled)
 // ---------------------------------------------------------------------------
 template <class P, bool KEEPK>
 __global__ __launch_bounds__(P::NT, 2) void k_correlate(
@@ -396,7 +401,6 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate(
         for (int a = 0; a < P::R1; a++)
             kreg[a] = krow[P::M1 * a + t];
     }
-    const float norm = 1.0f / ((float) P::N * (float) P::N);
     float *prow = plane + (size_t) z * (size_t) rlen;
     const int shift = 2 * halfwidth;
     PlaneStore<P> put(t, shift);
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate(
                 else
                     return afft::cmul_conj(dreg[a % H], krow_l[P::M1 * a + t]);
             },
-            [&](int n, c32 v) { put(rsrc, n - t, (v.x * v.x + v.y * v.y) * norm); });
+            [&](int n, c32 v) { put(rsrc, n - t, v.x * v.x + v.y * v.y); });
         __syncthreads(); // pass-3 reads done before the next block's pass-1 writes
     }
 }
@@ -487,7 +491,6 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
         for (int k = 0; k < 3; k++)
             w2.B[k] = pw2[(w2.NA + k) * P::R3 + (t % P::R3)];
     }
-    const float norm = 1.0f / ((float) P::N * (float) P::N);
     float *prow = plane + (size_t) z * (size_t) rlen;
     const int shift = 2 * halfwidth;
     PlaneStore<P> put(t, shift);
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
                         dreg[a] = D[P::M1 * a + t];
                 }
             },
-            [&](int n, c32 v) { put(rsrc, n - t, (v.x * v.x + v.y * v.y) * norm); });
+            [&](int n, c32 v) { put(rsrc, n - t, v.x * v.x + v.y * v.y); });
         __syncthreads();
     }
 }
