@@ -452,7 +452,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
     const c32 *__restrict__ bank, const c32 *__restrict__ blockfft,
     const int64_t *__restrict__ blk_col, const int *__restrict__ blk_ncols, int nblk, int chunk,
     float *__restrict__ plane, int64_t rlen, int halfwidth, const c32 *__restrict__ pw1,
-    const c32 *__restrict__ pw2)
+    const c32 *__restrict__ pw2, int numz, int tile_z, int tile_c)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     c32 *lds = reinterpret_cast<c32 *>(smem);
@@ -462,8 +462,26 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
     constexpr int H = P::R1 / 2;
 
     const int t = threadIdx.x;
-    const int z = blockIdx.x;
-    const int b0 = blockIdx.y * chunk;
+    int z, cy;
+    if (tile_z > 0) {
+        // One-dimensional grid, dealt round-robin over the 8 XCDs by the hardware: the
+        // workgroups an XCD holds at one time come from one tile of tile_z templates x
+        // tile_c chunks, so its L2 keeps tile_z template rows and tile_c block spectra
+        // instead of cycling through the whole bank.
+        const int nchunks = (nblk + chunk - 1) / chunk;
+        const int tiles_z = (numz + tile_z - 1) / tile_z;
+        const int per = tile_z * tile_c;
+        const int x = blockIdx.x % 8, sq = blockIdx.x / 8;
+        const int tile = (sq / per) * 8 + x, p = sq % per;
+        z = (tile % tiles_z) * tile_z + p % tile_z;
+        cy = (tile / tiles_z) * tile_c + p / tile_z;
+        if (z >= numz || cy >= nchunks)
+            return;
+    } else {
+        z = blockIdx.x;
+        cy = blockIdx.y;
+    }
+    const int b0 = cy * chunk;
     const int b1 = min(b0 + chunk, nblk);
     if (b0 >= b1)
         return;
