@@ -220,6 +220,32 @@ def test_injected_pulsar_recovered_at_known_rz(gpu):
     assert 0.7 * amp * amp <= best["power"] <= 1.4 * amp * amp
 
 
+def test_tiled_correlate_grid_equals_plain_grid(gpu, monkeypatch):
+    """Plane generation maps workgroups to (template, chunk) pairs in tiles per XCD when
+    the grid is large.  Any mapping must give the same plane: compare the default with
+    the plain two-dimensional grid and with odd tile shapes, bit for bit (hits carry the
+    summed powers; plane rows are read back directly)."""
+    import os
+    numbins = 1 << 21                       # 561 blocks -> 36 chunks x 201 templates: tiled by default
+    fft = synth.noise_fft(numbins, 21, lines=[(300000.5, 64.0, 10.0), (1200000.25, -150.0, 9.0)])
+    setup = gpu.configure(numbins, 2 * numbins, 64e-6, 200, 8, fhi=1e9)
+    gpu.load_fft(fft)
+    assert setup.numz * ((setup.num_search_blocks + setup.num_prepop_blocks + 15) // 16) >= 4096
+    monkeypatch.delenv("ACCELGPU_CORR_TZ", raising=False)
+    monkeypatch.delenv("ACCELGPU_CORR_TC", raising=False)
+    ref_hits = gpu.run()
+    rows = [(0, 0), (100, 2 * 300000 - 64), (setup.numz - 1, setup.rlen - 40000)]
+    ref_rows = [gpu.get_plane(z, c, 30000).copy() for z, c in rows]
+    assert len(ref_hits) > 0
+    for tz, tc in ((0, 1), (1, 1), (3, 5), (7, 64), (64, 3)):
+        monkeypatch.setenv("ACCELGPU_CORR_TZ", str(tz))
+        monkeypatch.setenv("ACCELGPU_CORR_TC", str(tc))
+        hits = gpu.run()
+        assert np.array_equal(hits, ref_hits), (tz, tc)
+        for (z, c), want in zip(rows, ref_rows):
+            assert np.array_equal(gpu.get_plane(z, c, 30000), want), (tz, tc, z)
+
+
 def test_async_launch_collect_equals_run(gpu):
     numbins = 1 << 17
     fft = synth.noise_fft(numbins, 11, lines=[(30000.0, -20.0, 9.0)])
