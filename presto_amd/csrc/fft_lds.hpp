@@ -29,6 +29,20 @@ __device__ __forceinline__ c32 cmul(c32 a, c32 b)
     return __builtin_elementwise_fma(a.yy, c32{-b.y, b.x}, t);
 }
 __device__ __forceinline__ c32 cmul_s(c32 a, c32 b) { return cmul(a, b); }
+// The same product for two values that both live in vector registers, with the second
+// instruction spelled out: a.y * (-b.y, b.x) + t as one packed fma whose operand selects
+// swap b's halves and whose modifier negates the low one.  (For register operands the
+// compiler builds (-b.y, b.x) with an xor and a move first; for constants it does not,
+// so cmul() stays the form for those.)
+__device__ __forceinline__ c32 cmul_v(c32 a, c32 b)
+{
+    const c32 t = a.xx * b;
+    c32 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(r)
+        : "v"(a), "v"(b), "v"(t));
+    return r;
+}
 // a * conj(b)
 __device__ __forceinline__ c32 cmul_conj(c32 a, c32 b)
 {
@@ -189,18 +203,14 @@ template <int R> struct TwoLevel {
 // registers) instead of being hoisted out of the caller's loop (R-1 live values).
 template <int R> __device__ __forceinline__ void launder(TwoLevel<R> &w)
 {
+    // (each value as one 64-bit register pair: laundered as two floats the halves come
+    // back in unrelated registers and every packed use needs two moves to pair them)
 #pragma unroll
-    for (int k = 0; k < TwoLevel<R>::NA; k++) {
-        float x = w.A[k].x, y = w.A[k].y;
-        asm volatile("" : "+v"(x), "+v"(y));
-        w.A[k] = c32{x, y};
-    }
+    for (int k = 0; k < TwoLevel<R>::NA; k++)
+        asm volatile("" : "+v"(w.A[k]));
 #pragma unroll
-    for (int k = 0; k < TwoLevel<R>::NB; k++) {
-        float x = w.B[k].x, y = w.B[k].y;
-        asm volatile("" : "+v"(x), "+v"(y));
-        w.B[k] = c32{x, y};
-    }
+    for (int k = 0; k < TwoLevel<R>::NB; k++)
+        asm volatile("" : "+v"(w.B[k]));
 }
 
 template <int R> __device__ __forceinline__ void apply_twiddles_2level(c32 *v, const TwoLevel<R> &w)
@@ -214,8 +224,8 @@ template <int R> __device__ __forceinline__ void apply_twiddles_2level(c32 *v, c
         else if (lo == 0)
             t = w.A[hi - 1];
         else
-            t = cmul(w.A[hi - 1], w.B[lo - 1]);
-        v[n] = cmul(v[n], t);
+            t = cmul_v(w.A[hi - 1], w.B[lo - 1]);
+        v[n] = cmul_v(v[n], t);
     }
 }
 
