@@ -529,8 +529,11 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
         // would pin another 2*R1 registers across the whole transform)
         const c32 *krow_l = krow;
         asm volatile("" : "+s"(krow_l));
-        afft::launder(w1);
-        // w2 is not laundered: its nine products stay hoisted out of the block loop (18 more registers)
+        // The twiddle generators are not laundered (afft::launder): the compiler forms all
+        // products of table entries once, ahead of the block loop, and keeps the R1-1 and
+        // R2-1 twiddles in registers for the whole chunk (238 VGPRs at 8192 points, 254 at
+        // 16384, no spills since the plane stores and template loads stopped needing
+        // address registers).
         // The template's spectrum: all loads issued before the first product (buffer
         // loads with the row offset in the scalar operand: no address arithmetic); the
         // products start as the values arrive, in order.  (Typed as plain global loads the
