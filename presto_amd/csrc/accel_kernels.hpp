@@ -430,7 +430,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate(
                 if constexpr (KEEPK)
                     return afft::cmul_conj(dreg[a % H], kreg[a]);
                 else
-                    return afft::cmul_conj(dreg[a % H], krow_l[P::M1 * a + t]);
+                    return afft::cmul_conj_v(dreg[a % H], krow_l[P::M1 * a + t]);
             },
             [&](int n, c32 v) { put(rsrc, n - t, v.x * v.x + v.y * v.y); });
         __syncthreads(); // pass-3 reads done before the next block's pass-1 writes
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
                 if constexpr (KEEPK)
                     return afft::cmul_conj(dreg[a % H], kreg[a]);
                 else
-                    return afft::cmul_conj(dreg[a % H], kv[a]);
+                    return afft::cmul_conj_v(dreg[a % H], kv[a]);
             },
             [&](int, int, c32 *v) { afft::apply_twiddles_2level<P::R1>(v, w1); },
             [&](int, int, c32 *v) { afft::apply_twiddles_2level<P::R2>(v, w2); },

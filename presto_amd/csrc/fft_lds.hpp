@@ -49,6 +49,17 @@ __device__ __forceinline__ c32 cmul_conj(c32 a, c32 b)
     const c32 t = a * b.xx;
     return __builtin_elementwise_fma(a.yx, c32{b.y, -b.y}, t);
 }
+// a * conj(b) for two values in vector registers, the second instruction spelled out as
+// in cmul_v(): (a.y, a.x) * (b.y, -b.y) + t.
+__device__ __forceinline__ c32 cmul_conj_v(c32 a, c32 b)
+{
+    const c32 t = a * b.xx;
+    c32 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
+        : "=v"(r)
+        : "v"(a), "v"(b), "v"(t));
+    return r;
+}
 template <int DIR> __device__ __forceinline__ c32 mul_i(c32 a)
 {
     return DIR > 0 ? c32{-a.y, a.x} : c32{a.y, -a.x};
