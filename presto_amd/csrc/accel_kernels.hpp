@@ -512,6 +512,11 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
     float *prow = plane + (size_t) z * (size_t) rlen;
     const int shift = 2 * halfwidth;
     PlaneStore<P> put(t, shift);
+    // every twiddle of passes 1 and 2, formed once and kept in registers for the whole
+    // chunk (238 VGPRs at 8192 points, 254 at 16384, no spills)
+    c32 W1[P::R1 - 1], W2[P::R2 - 1];
+    afft::expand_twiddles<P::R1>(W1, w1);
+    afft::expand_twiddles<P::R2>(W2, w2);
     c32 dreg[H];
     {
         const c32 *D = blockfft + (size_t) b0 * NF;
@@ -529,11 +534,6 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
         // would pin another 2*R1 registers across the whole transform)
         const c32 *krow_l = krow;
         asm volatile("" : "+s"(krow_l));
-        // The twiddle generators are not laundered (afft::launder): the compiler forms all
-        // products of table entries once, ahead of the block loop, and keeps the R1-1 and
-        // R2-1 twiddles in registers for the whole chunk (238 VGPRs at 8192 points, 254 at
-        // 16384, no spills since the plane stores and template loads stopped needing
-        // address registers).
         // The template's spectrum: all loads issued before the first product (buffer
         // loads with the row offset in the scalar operand: no address arithmetic); the
         // products start as the values arrive, in order.  (Typed as plain global loads the
@@ -558,8 +558,8 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
                 else
                     return afft::cmul_conj_v(dreg[a % H], kv[a]);
             },
-            [&](int, int, c32 *v) { afft::apply_twiddles_2level<P::R1>(v, w1); },
-            [&](int, int, c32 *v) { afft::apply_twiddles_2level<P::R2>(v, w2); },
+            [&](int, int, c32 *v) { afft::apply_twiddles_full<P::R1>(v, W1); },
+            [&](int, int, c32 *v) { afft::apply_twiddles_full<P::R2>(v, W2); },
             [&] {
                 // the block spectrum is used up by pass 1: fetch the next block's into the
                 // same registers now, so that it arrives during passes 2 and 3

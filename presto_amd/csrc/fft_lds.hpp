@@ -224,6 +224,23 @@ template <int R> __device__ __forceinline__ void launder(TwoLevel<R> &w)
         asm volatile("" : "+v"(w.B[k]));
 }
 
+// All R-1 twiddles w^1 .. w^(R-1) from the two tables, for kernels that keep them in
+// registers for many transforms.
+template <int R> __device__ __forceinline__ void expand_twiddles(c32 *full, const TwoLevel<R> &w)
+{
+#pragma unroll
+    for (int n = 1; n < R; n++) {
+        const int hi = n >> 2, lo = n & 3;
+        full[n - 1] = hi == 0 ? w.B[lo - 1] : lo == 0 ? w.A[hi - 1] : cmul_v(w.A[hi - 1], w.B[lo - 1]);
+    }
+}
+template <int R> __device__ __forceinline__ void apply_twiddles_full(c32 *v, const c32 *full)
+{
+#pragma unroll
+    for (int n = 1; n < R; n++)
+        v[n] = cmul_v(v[n], full[n - 1]);
+}
+
 template <int R> __device__ __forceinline__ void apply_twiddles_2level(c32 *v, const TwoLevel<R> &w)
 {
 #pragma unroll
