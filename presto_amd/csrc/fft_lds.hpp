@@ -234,11 +234,25 @@ template <int R> __device__ __forceinline__ void expand_twiddles(c32 *full, cons
         full[n - 1] = hi == 0 ? w.B[lo - 1] : lo == 0 ? w.A[hi - 1] : cmul_v(w.A[hi - 1], w.B[lo - 1]);
     }
 }
+// (in groups of four: the four first halves, then the four fused halves, so that no
+// instruction reads the result of the one right before it -- that costs a wait state)
 template <int R> __device__ __forceinline__ void apply_twiddles_full(c32 *v, const c32 *full)
 {
+    static_assert(R % 4 == 0, "radix is a multiple of four");
 #pragma unroll
-    for (int n = 1; n < R; n++)
-        v[n] = cmul_v(v[n], full[n - 1]);
+    for (int n0 = 0; n0 < R; n0 += 4) {
+        c32 t[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (n0 + k > 0)
+                t[k] = v[n0 + k].xx * full[n0 + k - 1];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (n0 + k > 0)
+                asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+                    : "=v"(v[n0 + k])
+                    : "v"(v[n0 + k]), "v"(full[n0 + k - 1]), "v"(t[k]));
+    }
 }
 
 template <int R> __device__ __forceinline__ void apply_twiddles_2level(c32 *v, const TwoLevel<R> &w)
