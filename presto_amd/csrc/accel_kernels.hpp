@@ -428,7 +428,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate(
             lds, tw1_l, tw2_l,
             [&](int, int a, int) {
                 if constexpr (KEEPK)
-                    return afft::cmul_conj(dreg[a % H], kreg[a]);
+                    return afft::cmul_conj_v(dreg[a % H], kreg[a]);
                 else
                     return afft::cmul_conj_v(dreg[a % H], krow_l[P::M1 * a + t]);
             },
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
             lds,
             [&](int, int a, int) {
                 if constexpr (KEEPK)
-                    return afft::cmul_conj(dreg[a % H], kreg[a]);
+                    return afft::cmul_conj_v(dreg[a % H], kreg[a]);
                 else
                     return afft::cmul_conj_v(dreg[a % H], kv[a]);
             },

@@ -345,12 +345,12 @@ __device__ __forceinline__ void fft3(c32 *lds, Tab tw1, Tab tw2, Load load, Stor
         [&](int, int b, c32 *v) {
 #pragma unroll
             for (int n1 = 1; n1 < P::R1; n1++)
-                v[n1] = cmul(v[n1], tw1[n1 * P::M1 + b]);
+                v[n1] = cmul_v(v[n1], tw1[n1 * P::M1 + b]);
         },
         [&](int, int d, c32 *v) {
 #pragma unroll
             for (int e = 1; e < P::R2; e++)
-                v[e] = cmul(v[e], tw2[e * P::R3 + d]);
+                v[e] = cmul_v(v[e], tw2[e * P::R3 + d]);
         },
         [] {}, store);
 }
