@@ -6,8 +6,9 @@
 //   k_fft_rows       forward FFT of each placed template (init_kernel, src/accel_utils.c:150)
 //   k_block_prep     per block: window fetch, exact block-median normalisation,
 //                    forward FFT (src/accel_utils.c:929-983)
-//   k_correlate      per (z, block): template multiply, inverse FFT, |.|^2 / N^2,
-//                    row store into the plane (src/accel_utils.c:1002-1051, 1076-1090)
+//   k_correlate_rr   per (z, block): template multiply, inverse FFT, |.|^2 / N^2,
+//   k_correlate      row store into the plane (src/accel_utils.c:1002-1051, 1076-1090);
+//                    twiddles in registers / read from tables
 //   k_harmsum        in-memory harmonic sum + threshold + wave-ballot compaction
 //                    (src/accel_utils.c:1160-1208, 1259-1299)
 #pragma once
