@@ -27,7 +27,7 @@ for name in sys.argv[1:] or ["cfg1", "cfg2", "cfg5", "cfg4"]:
     tm = g.timings()
     alg = 4.0 * (1 + SUMF2[nh]) * setup.numz * 7470 * setup.num_search_blocks
     hs = tm["harmsum"]["total_ms"]
-    print("%s: 2^%d bins zmax %d numharm %d: plane %.1f GB, %d blocks; search %.1f ms wall; prep %.2f correlate %.1f "
+    print("%s: 2^%d bins zmax %d numharm %d: plane %.1f GB, %d blocks; search %.1f ms wall; prep %.2f correlate %.3f "
           "harmsum %.1f ms = %.0f GB/s (%.1f%% of 8 TB/s); %d hits" % (
               name, int(np.log2(numbins)), zmax, nh, setup.plane_bytes / 1e9, setup.num_search_blocks, 1e3 * wall,
               tm["block_prep"]["total_ms"], tm["correlate"]["total_ms"], hs, alg / hs / 1e6, alg / hs / 1e6 / 80,
