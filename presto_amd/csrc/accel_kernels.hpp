@@ -670,10 +670,16 @@ __global__ __launch_bounds__(256) void k_harmsum(
             }
         }
         const uint32_t chg = NH > 0 ? rowchg[zi] : 0u;
+        // the row's offsets all at once (wide scalar loads, one latency) rather than one
+        // scalar load and wait inside each taken branch
+        int64_t ro[NHS];
+#pragma unroll
+        for (int i = 0; i < NH; i++)
+            ro[i] = rowoff[(size_t) zi * NHS + i];
 #pragma unroll
         for (int i = 0; i < NH; i++) {
             if (chg & (1u << i)) {
-                const char *row = pbytes + rowoff[(size_t) zi * NHS + i];
+                const char *row = pbytes + ro[i];
 #pragma unroll
                 for (int c = 0; c < C; c++)
                     v[i][c] = *reinterpret_cast<const float *>(row + off[i][c]);
