@@ -448,7 +448,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate(
 //                      then three rows exp(+2*pi*i*b*lo/N), lo = 1..3
 //   pw2: [R2/4+2][R3]  the same for exp(+2*pi*i*d*e/M1)
 // ---------------------------------------------------------------------------
-template <class P, bool KEEPK, int SER>
+template <class P, bool KEEPK, int SER, bool ZL = false>
 __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
     const c32 *__restrict__ bank, const c32 *__restrict__ blockfft,
     const int64_t *__restrict__ blk_col, const int *__restrict__ blk_ncols, int nblk, int chunk,
@@ -463,29 +463,34 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
     constexpr int H = P::R1 / 2;
 
     const int t = threadIdx.x;
-    int z, cy;
+    // ZL: a workgroup owns one block and a chunk of templates (the block's spectrum stays
+    // in registers, the template row changes per transform); otherwise one template and a
+    // chunk of blocks.  `ia` indexes the owned item, `cy` the chunk of the others.
+    const int na = ZL ? nblk : numz, nitems = ZL ? numz : nblk;
+    const int nchunks = (nitems + chunk - 1) / chunk;
+    int ia, cy;
     if (tile_z > 0) {
         // One-dimensional grid, dealt round-robin over the 8 XCDs by the hardware: the
-        // workgroups an XCD holds at one time come from one tile of tile_z templates x
-        // tile_c chunks, so its L2 keeps tile_z template rows and tile_c block spectra
-        // instead of cycling through the whole bank.
-        const int nchunks = (nblk + chunk - 1) / chunk;
-        const int tiles_z = (numz + tile_z - 1) / tile_z;
+        // workgroups an XCD holds at one time come from one tile of tile_z owned items x
+        // tile_c chunks, so its L2 keeps the few template rows and block spectra of that
+        // tile instead of cycling through the whole bank.
+        const int tiles_a = (na + tile_z - 1) / tile_z;
         const int per = tile_z * tile_c;
         const int x = blockIdx.x % 8, sq = blockIdx.x / 8;
         const int tile = (sq / per) * 8 + x, p = sq % per;
-        z = (tile % tiles_z) * tile_z + p % tile_z;
-        cy = (tile / tiles_z) * tile_c + p / tile_z;
-        if (z >= numz || cy >= nchunks)
+        ia = (tile % tiles_a) * tile_z + p % tile_z;
+        cy = (tile / tiles_a) * tile_c + p / tile_z;
+        if (ia >= na || cy >= nchunks)
             return;
     } else {
-        z = blockIdx.x;
+        ia = blockIdx.x;
         cy = blockIdx.y;
     }
     const int b0 = cy * chunk;
-    const int b1 = min(b0 + chunk, nblk);
+    const int b1 = min(b0 + chunk, nitems);
     if (b0 >= b1)
         return;
+    const int z = ZL ? b0 : ia; // ZL: the first template of the chunk
 
     const c32 *krow = bank + (size_t) z * P::N;
     c32 kreg[KEEPK ? P::R1 : 1];
@@ -520,20 +525,21 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
     afft::expand_twiddles<P::R2>(W2, w2);
     c32 dreg[H];
     {
-        const c32 *D = blockfft + (size_t) b0 * NF;
+        const c32 *D = blockfft + (size_t) (ZL ? ia : b0) * NF;
 #pragma unroll
         for (int a = 0; a < H; a++)
             dreg[a] = D[P::M1 * a + t];
     }
 
-    for (int blk = b0; blk < b1; blk++) {
-        float *out = prow + blk_col[blk];
+    for (int it = b0; it < b1; it++) {
+        const int blk = ZL ? ia : it;
+        float *out = (ZL ? plane + (size_t) it * (size_t) rlen : prow) + blk_col[blk];
         const int ncols = blk_ncols[blk];
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, ncols * 4, 0x00020000);
         put.refresh();
         // launder the pointer: the loads must stay inside the loop (hoisted, they
         // would pin another 2*R1 registers across the whole transform)
-        const c32 *krow_l = krow;
+        const c32 *krow_l = ZL ? bank + (size_t) it * P::N : krow;
         asm volatile("" : "+s"(krow_l));
         // The template's spectrum: all loads issued before the first product (buffer
         // loads with the row offset in the scalar operand: no address arithmetic); the
@@ -564,8 +570,8 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
             [&] {
                 // the block spectrum is used up by pass 1: fetch the next block's into the
                 // same registers now, so that it arrives during passes 2 and 3
-                if (blk + 1 < b1) {
-                    const c32 *D = blockfft + (size_t) (blk + 1) * NF;
+                if (!ZL && it + 1 < b1) {
+                    const c32 *D = blockfft + (size_t) (it + 1) * NF;
 #pragma unroll
                     for (int a = 0; a < H; a++)
                         dreg[a] = D[P::M1 * a + t];
