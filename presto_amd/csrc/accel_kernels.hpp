@@ -439,11 +439,13 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate(
 }
 
 // ---------------------------------------------------------------------------
-// Correlation, register-resident form.  Same arithmetic as k_correlate, but per
-// thread the template's spectrum (R1 values) and the twiddle generators (five
-// powers for pass 1, four for pass 2) stay in registers for the whole chunk of
-// blocks.  Global traffic per transform drops from ~160 KB to the 32 KB block
-// spectrum.
+// Correlation, register-resident form.  Same arithmetic as k_correlate, but every
+// twiddle of passes 1 and 2 is expanded once per workgroup from two short exact tables
+// and stays in registers for the whole chunk of transforms, and (ZL) so does the block
+// spectrum: a workgroup owns one block and loops over a chunk of templates.  Global
+// traffic per transform drops from ~160 KB to the 64 KB template row.  KEEPK (template
+// row in registers too, for the block loop) does not fit the register file and is kept
+// only as a compile-time experiment.
 //   pw1: [R1/4+2][M1]  rows 0..R1/4-2: exp(+2*pi*i*b*4*hi/N), hi = 1..R1/4-1;
 //                      then three rows exp(+2*pi*i*b*lo/N), lo = 1..3
 //   pw2: [R2/4+2][R3]  the same for exp(+2*pi*i*d*e/M1)
@@ -518,8 +520,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
     float *prow = plane + (size_t) z * (size_t) rlen;
     const int shift = 2 * halfwidth;
     PlaneStore<P> put(t, shift);
-    // every twiddle of passes 1 and 2, formed once and kept in registers for the whole
-    // chunk (238 VGPRs at 8192 points, 254 at 16384, no spills)
+    // every twiddle of passes 1 and 2, formed once and kept in registers for the whole chunk
     c32 W1[P::R1 - 1], W2[P::R2 - 1];
     afft::expand_twiddles<P::R1>(W1, w1);
     afft::expand_twiddles<P::R2>(W2, w2);
