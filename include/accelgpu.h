@@ -82,7 +82,33 @@ int accelgpu_create(accelgpu_ctx **ctx, int device);
 void accelgpu_destroy(accelgpu_ctx *ctx);
 /* Use the caller's hipStream_t instead of the context's own (NULL restores it). */
 int accelgpu_set_stream(accelgpu_ctx *ctx, void *hip_stream);
+/* Waits for everything the context has queued, uploads included. */
 int accelgpu_synchronize(accelgpu_ctx *ctx);
+
+/* Launch-shape knobs, by name.  The defaults are the measured optima; a context reads
+ * the environment overrides ACCELGPU_<NAME IN CAPITALS> once, in accelgpu_create(), and
+ * nothing on the launch path reads the environment afterwards.  Results never depend on
+ * a knob (tests compare them bit for bit); only with nothing in flight.
+ *   corr_rr        1   plane generation: register-twiddle kernel (0: table form)
+ *   corr_zl        1   ... one block per workgroup, loop over templates (0: the reverse)
+ *   corr_chunk     0   ... transforms per workgroup (0: 16, fewer on small grids)
+ *   corr_tz, _tc  -1,16 ... XCD tile of the grid: owned items x chunks (-1: 4 on large
+ *                      grids, plain 2-D grid on small ones; 0: plain grid)
+ *   hs_xcd_remap   1   harmonic sum: one contiguous run of columns per XCD
+ *   hs_lds         0   ... bytes of dynamic LDS per workgroup (caps the waves per CU)
+ *   hs_lean_from   6   ... register-lean kernel from this many stages on
+ *   hs_j          -1   ... column pairs per thread (-1: by number of stages)
+ *   hs_chunk_blocks 0  fill and sum the plane in chunks of this many search blocks
+ *                      (0: the whole plane at once)
+ *   std_table      0   standard mode: table-form correlate at the fundamental's length too
+ *   std_blocks     0   standard mode: search blocks per pass (0: what the scratch holds)
+ *   opt_nt       512   candidate optimisation: threads per workgroup
+ *   use_graph      1   small searches are launched as one captured graph
+ *   hits_cap   2^20    records in each device hit buffer (set: reallocates both; they
+ *                      grow on their own when a search overflows them)
+ * ref: none (the reference's only run-time knob is -ncpus). */
+int accelgpu_set_tuning(accelgpu_ctx *ctx, const char *name, int value);
+int accelgpu_get_tuning(accelgpu_ctx *ctx, const char *name, int *value);
 
 /* ---- host-side scalar helpers (no GPU needed) --------------------------- */
 /* ref: z_resp_halfwidth(z, LOWACC), src/responses.c:29-65 */
@@ -119,8 +145,21 @@ int accelgpu_get_kernel(accelgpu_ctx *ctx, int zind, float *out_complex);
  * ref: the mmap of the .fft, src/accel_utils.c:1497-1522,
  * and get_fourier_amplitudes(), :848-877. */
 int accelgpu_load_fft(accelgpu_ctx *ctx, const float *fft_complex_host, int64_t numbins);
-/* Same, for a spectrum already in device memory (not copied, not owned). */
+/* Same, for a spectrum already in device memory (not copied, not owned; it must stay
+ * valid and unchanged until the search launched on it has been collected). */
 int accelgpu_load_fft_device(accelgpu_ctx *ctx, const void *fft_complex_dev, int64_t numbins);
+/* Page-locked host memory, the kind accelgpu_load_fft_async() copies from at the full
+ * PCIe rate without a staging copy: read the .fft file straight into it.
+ * ref: the reference mmaps the file instead (src/accel_utils.c:1497-1522). */
+int accelgpu_host_alloc(void **ptr, size_t bytes);
+int accelgpu_host_free(void *ptr);
+/* accelgpu_load_fft() that returns at once: the copy runs on the copy engine beside
+ * whatever searches are in flight, and the launch that reads this spectrum waits for it
+ * on the device, so the host never does.  `fft_complex_host` must be page-locked
+ * (accelgpu_host_alloc, hipHostMalloc, hipHostRegister) and stay unchanged until the
+ * search launched on it has been collected (or accelgpu_synchronize() has returned).
+ * ref: as accelgpu_load_fft. */
+int accelgpu_load_fft_async(accelgpu_ctx *ctx, const float *fft_complex_host, int64_t numbins);
 
 /* Time-series input: uploads n float samples, transforms them on the device into
  * the packed .fft layout (bin 0 = DC, Nyquist) and, if `deredden` is non-zero,
@@ -203,7 +242,13 @@ int accelgpu_run(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits, int64_
  * and returns the sorted hits.  At most two launches are in flight; they are
  * collected in launch order.  A launched search keeps reading the spectrum that
  * was current at its launch: in-place changes of that spectrum are refused until
- * it is collected, loading another one is not. */
+ * it is collected, loading another one is not.
+ * A trial leaves the queue only when its hits have been handed over: if _collect
+ * returns ACCELGPU_ERR_OVERFLOW (*n_hits > max_hits) the same call with a larger
+ * buffer returns them.  A trial with more hits than the device buffer holds is run
+ * again by _collect itself into a larger one (regenerating its plane from its own
+ * spectrum if a later trial has been launched meanwhile), so the caller never sees
+ * that case. */
 int accelgpu_run_launch(accelgpu_ctx *ctx);
 int accelgpu_run_collect(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits,
                          int64_t *n_hits);

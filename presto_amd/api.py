@@ -5,6 +5,7 @@ Method names mirror the reference functions they stand in for
 inmem_add_ffdotpows, search_ffdotpows; reference include/accel.h:116-147).
 There is no CPU fallback: if the library is missing, loading fails loudly.
 """
+import collections
 import ctypes as C
 import os
 import subprocess
@@ -76,6 +77,11 @@ def load_library():
     L.accelgpu_get_kernel.argtypes = [vp, i, vp]
     L.accelgpu_load_fft.argtypes = [vp, vp, i64]
     L.accelgpu_load_fft_device.argtypes = [vp, vp, i64]
+    L.accelgpu_load_fft_async.argtypes = [vp, vp, i64]
+    L.accelgpu_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
+    L.accelgpu_host_free.argtypes = [vp]
+    L.accelgpu_set_tuning.argtypes = [vp, C.c_char_p, i]
+    L.accelgpu_get_tuning.argtypes = [vp, C.c_char_p, C.POINTER(i)]
     L.accelgpu_load_dat.argtypes = [vp, vp, i64, i]
     L.accelgpu_deredden.argtypes = [vp]
     L.accelgpu_rednoise.argtypes = [vp, i, i, d, d]
@@ -222,6 +228,29 @@ def replay_candidates(setup, hits):
     return cands[:nc.value].copy(), sig[:n], added[:n]
 
 
+class PinnedSpectrum:
+    """complex64[numbins] in page-locked host memory (accelgpu_host_alloc): what
+    AccelSearchGPU.load_fft_async() uploads from without the host waiting."""
+
+    def __init__(self, numbins):
+        self._p = C.c_void_p()
+        _check(load_library().accelgpu_host_alloc(C.byref(self._p), int(numbins) * 8))
+        buf = (C.c_float * (2 * int(numbins))).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=np.complex64)
+
+    def free(self):
+        if self._p:
+            self.array = None
+            load_library().accelgpu_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class AccelSearchGPU:
     """One search context on one GPU."""
 
@@ -230,7 +259,12 @@ class AccelSearchGPU:
         self._h = C.c_void_p()
         _check(self.L.accelgpu_create(C.byref(self._h), int(device)))
         self.setup = None
-        self._keep = None
+        # objects that own the memory queued work reads: the spectrum loaded for the next
+        # launch, one per launch in flight, and the one of the search collected last
+        # (which a launched optimisation may still read)
+        self._keep_next = None
+        self._keep_flight = collections.deque()
+        self._keep_collected = None
 
     def close(self):
         if self._h:
@@ -284,9 +318,24 @@ class AccelSearchGPU:
         return out
 
     def load_fft_device(self, dev_ptr, numbins, keepalive=None):
-        """Use a spectrum already in device memory (e.g. a torch tensor's data_ptr())."""
-        self._keep = keepalive
+        """Use a spectrum already in device memory (e.g. a torch tensor's data_ptr());
+        `keepalive` (the tensor) is held until the search launched on it has been
+        collected and the next one after it too (its optimisation may still read it)."""
         _check(self.L.accelgpu_load_fft_device(self._h, C.c_void_p(dev_ptr), int(numbins)))
+        self._keep_next = keepalive
+
+    def load_fft_async(self, pinned):
+        """Upload from a PinnedSpectrum without waiting; the launch waits on the device."""
+        _check(self.L.accelgpu_load_fft_async(self._h, C.c_void_p(pinned._p.value), pinned.array.size))
+        self._keep_next = pinned
+
+    def set_tuning(self, name, value):
+        _check(self.L.accelgpu_set_tuning(self._h, name.encode(), int(value)))
+
+    def get_tuning(self, name):
+        v = C.c_int(0)
+        _check(self.L.accelgpu_get_tuning(self._h, name.encode(), C.byref(v)))
+        return v.value
 
     def configure(self, numbins, N, dt, zmax, numharm, sigma=2.0, flo=1.0, fhi=10000.0, lobin=0,
                   photon_nph=0.0, norm_type=0, inmem=True):
@@ -324,14 +373,18 @@ class AccelSearchGPU:
         return self._hits_call(self.L.accelgpu_search_plane, max_hits)
 
     def run(self, max_hits=1 << 20):
-        _check(self.L.accelgpu_run_launch(self._h))
-        return self._hits_call(self.L.accelgpu_run_collect, max_hits)
+        self.run_launch()
+        return self.run_collect(max_hits)
 
     def run_launch(self):
         _check(self.L.accelgpu_run_launch(self._h))
+        self._keep_flight.append(self._keep_next)
 
     def run_collect(self, max_hits=1 << 20):
-        return self._hits_call(self.L.accelgpu_run_collect, max_hits)
+        hits = self._hits_call(self.L.accelgpu_run_collect, max_hits)
+        if self._keep_flight:
+            self._keep_collected = self._keep_flight.popleft()
+        return hits
 
     def search(self, max_hits=1 << 20):
         """Whole search of the loaded spectrum: (hits, cands, sigma, added)."""

@@ -259,7 +259,10 @@ int replay(const accelgpu_setup *s, const accelgpu_hit *hits, int64_t n_hits,
     std::vector<double> pmax; // running maximum of list[..].r, same length as list
     list.reserve(1024);
     pmax.reserve(1024);
-    const bool linear_walk = std::getenv("ACCELGPU_REPLAY_LINEAR") != nullptr; // A/B against the plain walk
+    // read once per process: ACCELGPU_REPLAY_LINEAR selects the plain list walk (the check
+    // for the binary search below), ACCELGPU_HOST_THREADS the threads that compute sigmas
+    static const bool linear_walk = std::getenv("ACCELGPU_REPLAY_LINEAR") != nullptr;
+    static const int env_threads = std::getenv("ACCELGPU_HOST_THREADS") ? std::atoi(std::getenv("ACCELGPU_HOST_THREADS")) : -1;
     const double zlo = s->zlo;
     for (int64_t i = 0; i < n_hits; i++)
         if (hits[i].stage < 0 || hits[i].stage >= s->numharmstages) {
@@ -277,8 +280,8 @@ int replay(const accelgpu_setup *s, const accelgpu_hit *hits, int64_t n_hits,
                                                       (double) s->numindep[hits[i].stage]);
     };
     int nthreads = (int) std::min<int64_t>(n_hits / 2048, 8);
-    if (const char *e = std::getenv("ACCELGPU_HOST_THREADS"))
-        nthreads = std::atoi(e);
+    if (env_threads >= 0)
+        nthreads = env_threads;
     nthreads = std::min<int>(nthreads, (int) std::max(1u, std::thread::hardware_concurrency()));
     if (nthreads <= 1) {
         sigma_range(0, n_hits);

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -69,9 +70,30 @@ template <class T> struct DevTemp {
 
 } // namespace
 
+// Launch-shape knobs.  Defaults are the measured optima; accelgpu_create() reads the
+// ACCELGPU_* environment overrides once, accelgpu_set_tuning() changes one by name
+// (A/B sweeps and tests).  Nothing on the launch path reads the environment.
+struct Tuning {
+    int corr_rr = 1;        // plane generation: 1 register-twiddle kernel, 0 table form
+    int corr_zl = 1;        // register form loops over templates (1) or over blocks (0)
+    int corr_chunk = 0;     // transforms per workgroup; 0: 16, fewer on small grids
+    int corr_tz = -1;       // XCD tile: owned items per tile; -1: 4 on large grids, plain grid otherwise; 0: plain grid
+    int corr_tc = 16;       // XCD tile: chunks per tile
+    int hs_xcd_remap = 1;   // harmonic sum: each XCD takes one contiguous run of columns
+    int hs_lds = 0;         // harmonic sum: bytes of dynamic LDS (caps the waves per CU)
+    int hs_lean_from = 6;   // harmonic sum: register-lean form from this many stages on
+    int hs_j = -1;          // harmonic sum: column pairs per thread; -1: by number of stages
+    int hs_chunk_blocks = 0; // fill + sum in chunks of this many search blocks; 0: whole plane at once
+    int std_table = 0;      // standard mode: table-form correlate also at the fundamental's length
+    int std_blocks = 0;     // standard mode: search blocks per pass; 0: as many as the scratch holds
+    int opt_nt = 512;       // candidate optimisation: threads per workgroup
+    int use_graph = 1;      // launch small searches as one captured graph
+};
+
 struct accelgpu_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    Tuning tune;
 
     // kernel bank
     int zmax = -1, numz = 0, fftlen = 0, halfwidth = 0;
@@ -89,6 +111,10 @@ struct accelgpu_ctx {
     c32 *d_own[kOwn] = {nullptr, nullptr, nullptr};
     size_t own_cap[kOwn] = {0, 0, 0};
     int cur_own = -1;                                // index of d_fft in d_own, -1: caller's buffer
+    // accelgpu_load_fft_async(): the copy into d_own[j] runs on the side stream; own_ready[j]
+    // is recorded behind it and own_pending[j] stays set until the host has waited for it
+    hipEvent_t own_ready[kOwn] = {nullptr, nullptr, nullptr};
+    bool own_pending[kOwn] = {false, false, false};
     int64_t numbins = 0;
     struct {
         const c32 *fft = nullptr;
@@ -149,13 +175,18 @@ struct accelgpu_ctx {
         const c32 *fft = nullptr;                    // the spectrum this launch reads
         int64_t numbins = 0;
         size_t prefetch = 0;                         // hits copied back speculatively at launch
+        size_t cap = 0;                              // room in d_hits / h_hits
+        uint64_t serial = 0;                         // which launch this is (see plane_serial)
     } slots[2];
     int head = 0, tail = 0, inflight = 0;            // FIFO of launched, uncollected trials
+    uint64_t launch_serial = 0;                      // launches so far
+    uint64_t plane_serial = 0;                       // the launch whose fundamental the plane holds
+    bool graph_stale = true;                         // a captured launch graph no longer matches the set-up
     hipStream_t copy_stream = nullptr;               // late D2H copies that must not queue behind kernels
     DevHit *d_hits = nullptr;
     DevHit *h_hits = nullptr;
     unsigned int *d_count = nullptr, *h_count = nullptr;
-    size_t hits_cap = 0;
+    size_t hits_cap = 0;                             // of the selected slot
 
     // scratch for the single-block getters
     float *d_tmp = nullptr;
@@ -177,10 +208,11 @@ struct accelgpu_ctx {
     };
     std::deque<SubBank> subbanks;
     std::map<int, Twiddles> tw_cache; // key 2*n + (dir > 0)
+    static constexpr int kStdBufs = 12;
     struct StdBuf {
         void *p = nullptr;
         size_t cap = 0;
-    } std_buf[8];
+    } std_buf[kStdBufs];
     // chirp-z filter spectrum for time series whose length is not a power of two
     c32 *d_blu_filter = nullptr;
     size_t blu_cap = 0;
@@ -287,6 +319,10 @@ int pick_own(accelgpu_ctx *ctx, int *idx)
     }
     if (ctx->d_own[*idx] && ctx->collected.fft == ctx->d_own[*idx])
         ctx->collected.valid = false;
+    if (ctx->own_pending[*idx]) { // an asynchronous upload into this buffer that nothing waited for
+        HIPCHK(hipEventSynchronize(ctx->own_ready[*idx]));
+        ctx->own_pending[*idx] = false;
+    }
     return ACCELGPU_OK;
 }
 
@@ -430,12 +466,12 @@ int corr_chunk(int preferred, int numz, int nblk)
 // workgroups round-robin over the 8 XCDs, and the kernel maps them so that the workgroups
 // one XCD holds at a time share tile_z template rows and tile_c chunks (4 x 16 measured
 // best on a 201 x 71 grid: 3.08 against 3.24 ms; 8 x 8 3.11, 2 x 32 3.08, 16 x 16 3.26).
-// tile_z = 0: plain two-dimensional grid.  ACCELGPU_CORR_TZ / _TC override.
-dim3 corr_grid(int numz, int nchunks, int *tile_z, int *tile_c)
+// tile_z = 0: plain two-dimensional grid.  Tuning corr_tz / corr_tc override.
+dim3 corr_grid(const Tuning &tn, int numz, int nchunks, int *tile_z, int *tile_c)
 {
-    int tz = (long long) numz * nchunks >= 4096 ? 4 : 0, tc = 16;
-    if (const char *e = getenv("ACCELGPU_CORR_TZ")) tz = atoi(e);
-    if (const char *e = getenv("ACCELGPU_CORR_TC")) tc = std::max(1, atoi(e));
+    int tz = (long long) numz * nchunks >= 4096 ? 4 : 0;
+    if (tn.corr_tz >= 0) tz = tn.corr_tz;
+    const int tc = std::max(1, tn.corr_tc);
     *tile_z = tz;
     *tile_c = tc;
     if (tz <= 0)
@@ -449,12 +485,12 @@ int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const i
 {
     // Register-resident twiddle form for both plans (measured on one device: 3.3 against
     // 5.8 ms per 2^23-point zmax 200 search, 83 against 116 ms per 2^24-point zmax 1200
-    // search).  ACCELGPU_CORR=0/1 forces one for A/B runs.
-    const char *variant = getenv("ACCELGPU_CORR");
-    const bool rr = variant ? atoi(variant) != 0 : true;
+    // search).  Tuning corr_rr = 0 selects the table form for A/B runs.
+    const Tuning &tn = ctx->tune;
+    const bool rr = tn.corr_rr != 0;
     int chunk = corr_chunk(rr ? 16 : 8, ctx->numz, nblk);   // blocks per workgroup (templates in the ZL form)
-    if (const char *e = getenv("ACCELGPU_CORR_CHUNK"))
-        chunk = std::max(1, atoi(e));
+    if (tn.corr_chunk > 0)
+        chunk = tn.corr_chunk;
     const dim3 grid(ctx->numz, (nblk + chunk - 1) / chunk);
     if (2 * ctx->halfwidth > 2048) { // the kernels' range-checked stores assume this
         set_error("template half width %d is beyond what the correlate kernels store", ctx->halfwidth);
@@ -466,17 +502,17 @@ int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const i
     // Register form: a workgroup owns one block and loops over a chunk of templates (the
     // block's spectrum stays in registers: a third less L2->L1 traffic per transform than
     // one template looping over blocks; 2.67 against 2.78 ms on a 201 x 1123 grid, chunks
-    // of 16 templates against 8: 2.75, 32: 2.81).  ACCELGPU_CORR_ZL=0 selects the other loop.
-    const bool zl = getenv("ACCELGPU_CORR_ZL") ? atoi(getenv("ACCELGPU_CORR_ZL")) != 0 : true;
+    // of 16 templates against 8: 2.75, 32: 2.81).  Tuning corr_zl = 0 selects the other loop.
+    const bool zl = tn.corr_zl != 0;
     int tile_z = 0, tile_c = 0;
     dim3 rgrid;
     if (zl) {
         chunk = corr_chunk(16, nblk, ctx->numz);
-        if (const char *e = getenv("ACCELGPU_CORR_CHUNK"))
-            chunk = std::max(1, atoi(e));
-        rgrid = corr_grid(nblk, (ctx->numz + chunk - 1) / chunk, &tile_z, &tile_c);
+        if (tn.corr_chunk > 0)
+            chunk = tn.corr_chunk;
+        rgrid = corr_grid(tn, nblk, (ctx->numz + chunk - 1) / chunk, &tile_z, &tile_c);
     } else {
-        rgrid = corr_grid(ctx->numz, (int) grid.y, &tile_z, &tile_c);
+        rgrid = corr_grid(tn, ctx->numz, (int) grid.y, &tile_z, &tile_c);
     }
 #define LAUNCH_RR(PLAN, ZL)                                                                    \
     hipLaunchKernelGGL((accelk::k_correlate_rr<PLAN, false, 16, ZL>), rgrid, dim3(PLAN::NT),   \
@@ -503,24 +539,32 @@ int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const i
     return prof_end(ctx, 1, &ep);
 }
 
+// Where a harmonic-sum launch compacts its threshold crossings.
+struct HitTarget {
+    DevHit *hits;
+    unsigned int *count;
+    size_t cap;
+};
+
 // J = column pairs per thread of the harmonic-sum kernel.
 template <bool DUMP, int J>
 int launch_harmsum_j(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, float *dump,
-                     int dump_stage)
+                     int dump_stage, const HitTarget &out, bool timed)
 {
     accelk::HarmParams prm;
     for (int i = 0; i < 6; i++)
         prm.powcut[i] = i < ctx->setup.numharmstages ? ctx->setup.powcut[i] : INFINITY;
     constexpr int C = J > 0 ? 2 * J : 1;
-    const int remap = getenv("ACCELGPU_NO_XCD_REMAP") ? 0 : 1;
-    const int lds_pad = getenv("ACCELGPU_HS_LDS") ? atoi(getenv("ACCELGPU_HS_LDS")) : 0; // occupancy experiments
+    const int remap = ctx->tune.hs_xcd_remap ? 1 : 0;
+    const int lds_pad = ctx->tune.hs_lds; // occupancy experiments
     unsigned ntiles = (unsigned) ((ncols + 256 * C - 1) / (256 * C));
     if (remap)
         ntiles = ((ntiles + 7) / 8) * 8;
     const dim3 grid(ntiles);
-    const unsigned int cap = (unsigned int) std::min<size_t>(ctx->hits_cap, 0xFFFFFFFFu);
+    const unsigned int cap = (unsigned int) std::min<size_t>(out.cap, 0xFFFFFFFFu);
     EventPair ep;
-    if (!DUMP) {
+    timed = timed && !DUMP;
+    if (timed) {
         int rc = prof_begin(ctx, 2, &ep);
         if (rc) return rc;
     }
@@ -535,17 +579,16 @@ int launch_harmsum_j(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols
     hipLaunchKernelGGL((accelk::k_harmsum<NS, C, DUMP>), grid, dim3(256), lds_pad, ctx->stream,     \
                        ctx->d_plane, ctx->setup.rlen, ctx->numz, col0, ncols, ctx->d_rowoff,   \
                        ctx->d_rowchg,                                                         \
-                       prm, ctx->d_hits, ctx->d_count, cap, dump, dump_stage, remap)
+                       prm, out.hits, out.count, cap, dump, dump_stage, remap)
 #define LAUNCH_HS_LEAN(NS)                                                                   \
     hipLaunchKernelGGL((accelk::k_harmsum_lean<NS, DUMP>), grid, dim3(256), lds_pad, ctx->stream,   \
                        ctx->d_plane, ctx->setup.rlen, ctx->numz, col0, ncols, ctx->d_rowoff,   \
                        ctx->d_rowchg,                                                         \
-                       prm, ctx->d_hits, ctx->d_count, cap, dump, dump_stage, remap)
+                       prm, out.hits, out.count, cap, dump, dump_stage, remap)
     // One column per thread and 31 sub-harmonics: the register-lean form keeps 7 waves
     // per SIMD in flight instead of 4 (measured 58 -> 78-80 % of the HBM peak); with 15
     // or fewer the plain form already runs 7-8 waves and the two time the same.
-    const int lean_from = getenv("ACCELGPU_HS_LEAN_FROM") ? atoi(getenv("ACCELGPU_HS_LEAN_FROM")) : 6;
-    const bool lean = C == 1 && nstages >= lean_from && nstages >= 3;
+    const bool lean = C == 1 && nstages >= ctx->tune.hs_lean_from && nstages >= 3;
     switch (nstages) {
     case 1: LAUNCH_HS(1); break;
     case 2: LAUNCH_HS(2); break;
@@ -560,14 +603,14 @@ int launch_harmsum_j(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols
 #undef LAUNCH_HS
 #undef LAUNCH_HS_LEAN
     HIPCHK(hipGetLastError());
-    if (!DUMP)
+    if (timed)
         return prof_end(ctx, 2, &ep);
     return ACCELGPU_OK;
 }
 
 template <bool DUMP>
 int launch_harmsum(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, float *dump,
-                   int dump_stage)
+                   int dump_stage, const HitTarget &out, bool timed = true)
 {
     // Few harmonics: little data per thread, so take it in 8-byte pieces, two
     // pairs per thread, to keep enough bytes in flight; many harmonics: one
@@ -576,13 +619,18 @@ int launch_harmsum(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, 
     // with two pairs against 44/49 % with one column; 4 harmonics 71.5 % with one pair
     // against 60.7 %; 8 harmonics 75 % with one column against 66 % with pairs)
     int j = nstages <= 2 ? 2 : nstages == 3 ? 1 : 0;
-    if (const char *e = getenv("ACCELGPU_HARM_J"))
-        j = atoi(e);
+    if (ctx->tune.hs_j >= 0)
+        j = ctx->tune.hs_j;
     if (j == 2)
-        return launch_harmsum_j<DUMP, 2>(ctx, nstages, col0, ncols, dump, dump_stage);
+        return launch_harmsum_j<DUMP, 2>(ctx, nstages, col0, ncols, dump, dump_stage, out, timed);
     if (j == 1)
-        return launch_harmsum_j<DUMP, 1>(ctx, nstages, col0, ncols, dump, dump_stage);
-    return launch_harmsum_j<DUMP, 0>(ctx, nstages, col0, ncols, dump, dump_stage);
+        return launch_harmsum_j<DUMP, 1>(ctx, nstages, col0, ncols, dump, dump_stage, out, timed);
+    return launch_harmsum_j<DUMP, 0>(ctx, nstages, col0, ncols, dump, dump_stage, out, timed);
+}
+
+HitTarget slot_target(const accelgpu_ctx *ctx)
+{
+    return HitTarget{ctx->d_hits, ctx->d_count, ctx->hits_cap};
 }
 
 void select_slot(accelgpu_ctx *ctx, int i)
@@ -591,29 +639,43 @@ void select_slot(accelgpu_ctx *ctx, int i)
     ctx->h_hits = ctx->slots[i].h_hits;
     ctx->d_count = ctx->slots[i].d_count;
     ctx->h_count = ctx->slots[i].h_count;
+    ctx->hits_cap = ctx->slots[i].cap;
 }
 
+// (Re)allocates one slot's hit buffers for exactly `want` records.  hipFree waits for the
+// device, so whatever is queued has finished when this returns.
+int resize_slot(accelgpu_ctx *ctx, int i, size_t want)
+{
+    accelgpu_ctx::HitSlot &sl = ctx->slots[i];
+    if (sl.d_hits) HIPCHK(hipFree(sl.d_hits));
+    if (sl.h_hits) HIPCHK(hipHostFree(sl.h_hits));
+    sl.d_hits = sl.h_hits = nullptr;
+    sl.cap = 0;
+    if (hipMalloc((void **) &sl.d_hits, want * sizeof(DevHit)) != hipSuccess ||
+        hipHostMalloc((void **) &sl.h_hits, want * sizeof(DevHit)) != hipSuccess) {
+        set_error("cannot allocate room for %zu hits", want);
+        return ACCELGPU_ERR_NOMEM;
+    }
+    sl.cap = want;
+    return ACCELGPU_OK;
+}
+
+// Both slots to at least `want` records (only with nothing in flight: a launched trial's
+// hits live in its slot).
 int reserve_hits(accelgpu_ctx *ctx, size_t want)
 {
-    if (ctx->hits_cap >= want)
+    if (ctx->slots[0].cap >= want && ctx->slots[1].cap >= want)
         return ACCELGPU_OK;
     if (ctx->inflight > 0) {
         set_error("cannot grow the hit buffers while %d launches are in flight", ctx->inflight);
         return ACCELGPU_ERR_ARG;
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->hits_cap = 0;
-    for (auto &sl : ctx->slots) {
-        if (sl.d_hits) HIPCHK(hipFree(sl.d_hits));
-        if (sl.h_hits) HIPCHK(hipHostFree(sl.h_hits));
-        sl.d_hits = sl.h_hits = nullptr;
-        if (hipMalloc((void **) &sl.d_hits, want * sizeof(DevHit)) != hipSuccess ||
-            hipHostMalloc((void **) &sl.h_hits, want * sizeof(DevHit)) != hipSuccess) {
-            set_error("cannot allocate room for %zu hits", want);
-            return ACCELGPU_ERR_NOMEM;
+    for (int i = 0; i < 2; i++)
+        if (ctx->slots[i].cap < want) {
+            int rc = resize_slot(ctx, i, want);
+            if (rc) return rc;
         }
-    }
-    ctx->hits_cap = want;
     select_slot(ctx, ctx->head);
     return ACCELGPU_OK;
 }
@@ -627,7 +689,27 @@ int need_plane(accelgpu_ctx *ctx)
     return ACCELGPU_OK;
 }
 
-int check_ready(accelgpu_ctx *ctx, bool need_fft)
+// The current spectrum may still be on its way (accelgpu_load_fft_async).  A launched
+// search waits for it on the device; everything else waits here, on the host.
+int settle_spectrum(accelgpu_ctx *ctx)
+{
+    const int j = ctx->cur_own;
+    if (j >= 0 && ctx->own_pending[j]) {
+        HIPCHK(hipEventSynchronize(ctx->own_ready[j]));
+        ctx->own_pending[j] = false;
+    }
+    return ACCELGPU_OK;
+}
+
+int spectrum_ready(accelgpu_ctx *ctx, hipStream_t st)
+{
+    const int j = ctx->cur_own;
+    if (j >= 0 && ctx->own_pending[j])
+        HIPCHK(hipStreamWaitEvent(st, ctx->own_ready[j], 0));
+    return ACCELGPU_OK;
+}
+
+int check_ready(accelgpu_ctx *ctx, bool need_fft, bool settle = true)
 {
     if (ctx->zmax < 0) {
         set_error("accelgpu_build_kernels() has not been called");
@@ -646,6 +728,8 @@ int check_ready(accelgpu_ctx *ctx, bool need_fft)
                   ctx->setup.zmax);
         return ACCELGPU_ERR_ARG;
     }
+    if (need_fft && settle)
+        return settle_spectrum(ctx);
     return ACCELGPU_OK;
 }
 
@@ -665,17 +749,27 @@ int queue_search(accelgpu_ctx *ctx)
     HIPCHK(hipMemsetAsync(ctx->d_count, 0, sizeof(unsigned int), ctx->stream));
     int rc = launch_harmsum<false>(ctx, ctx->setup.numharmstages,
                                    ctx->col0 + (int64_t) ctx->range_first * ACCELGPU_USELEN,
-                                   (int64_t) ctx->range_count * ACCELGPU_USELEN, nullptr, 0);
+                                   (int64_t) ctx->range_count * ACCELGPU_USELEN, nullptr, 0,
+                                   slot_target(ctx));
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(ctx->h_count, ctx->d_count, sizeof(unsigned int), hipMemcpyDeviceToHost,
                           ctx->stream));
     return ACCELGPU_OK;
 }
 
-// Waits for the search launched into slot `si`, re-running it with a larger
-// buffer if the compaction overflowed (possible only when no later trial has
-// been queued, because the plane must still hold this trial), then sorts into
-// the reference's visiting order.
+// The reference's visiting order (block, stage, z row, r) as one integer per hit.
+inline uint64_t visit_key(int64_t rind, uint32_t stage, uint32_t zind, int64_t col0)
+{
+    const uint64_t c = (uint64_t) (rind - col0);
+    const uint64_t block = c / ACCELGPU_USELEN, col = c % ACCELGPU_USELEN;      // col < 2^13
+    return (((block * 8 + stage) * 2048 + zind) << 13) | col;                  // stage < 2^3, zind < 2^11
+}
+
+// Waits for the search launched into slot `si` and returns its hits sorted into the
+// reference's visiting order.  If the compaction overflowed the slot's buffer the search
+// is run again into a larger one: from the plane if it still holds this trial, after
+// regenerating the plane from this trial's spectrum if a later trial has been launched
+// since (that trial has finished by then, and its hits wait in the other slot).
 int finish_search(accelgpu_ctx *ctx, int si, accelgpu_hit *hits, int64_t max_hits, int64_t *n_hits)
 {
     accelgpu_ctx::HitSlot &sl = ctx->slots[si];
@@ -684,22 +778,31 @@ int finish_search(accelgpu_ctx *ctx, int si, accelgpu_hit *hits, int64_t max_hit
     size_t n = *sl.h_count;
     size_t have = std::min(sl.prefetch, n);
     sl.prefetch = 0;
-    if (n > ctx->hits_cap) {
-        if (ctx->inflight > 0) {
-            *n_hits = (int64_t) n;
-            set_error("%zu hits overflow the %zu-entry device buffer and a later trial is already "
-                      "queued: collect it, then run this trial again on its own", n, ctx->hits_cap);
-            return ACCELGPU_ERR_OVERFLOW;
-        }
-        int rc = reserve_hits(ctx, n + n / 4 + 1024);
+    if (n > sl.cap) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->copy_stream));
+        int rc = resize_slot(ctx, si, n + n / 4 + 1024);
         if (rc) return rc;
         select_slot(ctx, si);
-        rc = queue_search(ctx);
+        const bool prof = ctx->profiling;
+        ctx->profiling = false; // a repeat is not one of the timed launches
+        if (ctx->plane_serial != sl.serial) {
+            const c32 *cur_fft = ctx->d_fft;
+            const int64_t cur_bins = ctx->numbins;
+            ctx->d_fft = sl.fft;
+            ctx->numbins = sl.numbins;
+            rc = queue_fill(ctx);
+            ctx->d_fft = cur_fft;
+            ctx->numbins = cur_bins;
+            if (!rc) ctx->plane_serial = sl.serial;
+        }
+        if (!rc) rc = queue_search(ctx);
+        ctx->profiling = prof;
         if (rc) return rc;
         HIPCHK(hipStreamSynchronize(ctx->stream));
         n = *ctx->h_count;
         have = 0;
-        if (n > ctx->hits_cap) {
+        if (n > sl.cap) {
             set_error("hit count changed between two runs of the same search");
             return ACCELGPU_ERR_HIP;
         }
@@ -714,16 +817,12 @@ int finish_search(accelgpu_ctx *ctx, int si, accelgpu_hit *hits, int64_t max_hit
         set_error("%zu hits but room for %lld: re-run with a larger buffer", n, (long long) max_hits);
         return ACCELGPU_ERR_OVERFLOW;
     }
-    // The reference's visiting order (block, stage, z row, r) as one integer key per hit:
-    // sort the keys, then write the hits out in that order.
+    // sort one key per hit, then write the hits out in that order
     const int64_t col0 = ctx->col0;
     std::vector<std::pair<uint64_t, uint32_t>> order(n);
     for (size_t i = 0; i < n; i++) {
         const DevHit &d = ctx->h_hits[i];
-        const uint64_t c = (uint64_t) (d.rind - col0);
-        const uint64_t block = c / ACCELGPU_USELEN, col = c % ACCELGPU_USELEN;      // col < 2^13
-        const uint64_t stage = d.stage_zind >> 16, zind = d.stage_zind & 0xFFFF;    // < 2^3, < 2^11
-        order[i] = {(((block * 8 + stage) * 2048 + zind) << 13) | col, (uint32_t) i};
+        order[i] = {visit_key(d.rind, d.stage_zind >> 16, d.stage_zind & 0xFFFF, col0), (uint32_t) i};
     }
     std::sort(order.begin(), order.end());
     for (size_t k = 0; k < n; k++) {
@@ -736,6 +835,35 @@ int finish_search(accelgpu_ctx *ctx, int si, accelgpu_hit *hits, int64_t max_hit
         h.block = (int32_t) ((d.rind - col0) / ACCELGPU_USELEN);
     }
     return ACCELGPU_OK;
+}
+
+// The tuning knobs by name, for accelgpu_set_tuning()/accelgpu_get_tuning() and the
+// environment overrides (ACCELGPU_ + the name in capitals) read once per context.
+struct TuneName {
+    const char *name;
+    int Tuning::*field;
+};
+const TuneName kTuneNames[] = {
+    {"corr_rr", &Tuning::corr_rr},           {"corr_zl", &Tuning::corr_zl},
+    {"corr_chunk", &Tuning::corr_chunk},     {"corr_tz", &Tuning::corr_tz},
+    {"corr_tc", &Tuning::corr_tc},           {"hs_xcd_remap", &Tuning::hs_xcd_remap},
+    {"hs_lds", &Tuning::hs_lds},             {"hs_lean_from", &Tuning::hs_lean_from},
+    {"hs_j", &Tuning::hs_j},                 {"hs_chunk_blocks", &Tuning::hs_chunk_blocks},
+    {"std_table", &Tuning::std_table},       {"std_blocks", &Tuning::std_blocks},
+    {"opt_nt", &Tuning::opt_nt},             {"use_graph", &Tuning::use_graph},
+};
+
+void tuning_from_env(Tuning *t)
+{
+    for (const TuneName &k : kTuneNames) {
+        char var[64] = "ACCELGPU_";
+        size_t n = strlen(var);
+        for (const char *p = k.name; *p && n + 1 < sizeof(var); p++)
+            var[n++] = (char) toupper((unsigned char) *p);
+        var[n] = 0;
+        if (const char *e = getenv(var))
+            t->*(k.field) = atoi(e);
+    }
 }
 
 } // namespace
@@ -793,8 +921,14 @@ int accelgpu_create(accelgpu_ctx **out, int device)
         return ACCELGPU_ERR_ARG;
     }
     HIPCHK(hipSetDevice(device));
-    accelgpu_ctx *ctx = new accelgpu_ctx();
+    // released on every early return below; handed to the caller at the end
+    struct Guard {
+        accelgpu_ctx *c;
+        ~Guard() { if (c) accelgpu_destroy(c); }
+    } guard{new accelgpu_ctx()};
+    accelgpu_ctx *ctx = guard.c;
     ctx->device = device;
+    tuning_from_env(&ctx->tune);
     HIPCHK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
@@ -813,6 +947,8 @@ int accelgpu_create(accelgpu_ctx **out, int device)
         HIPCHK(hipEventCreateWithFlags(&sl.kernels, hipEventDisableTiming));
     }
     HIPCHK(hipEventCreateWithFlags(&ctx->opt.done, hipEventDisableTiming));
+    for (hipEvent_t &e : ctx->own_ready)
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipMalloc((void **) &ctx->d_one_lobin, sizeof(int64_t)));
     HIPCHK(hipMalloc((void **) &ctx->d_one_col, sizeof(int64_t)));
     HIPCHK(hipMalloc((void **) &ctx->d_one_numdata, sizeof(int)));
@@ -834,6 +970,7 @@ int accelgpu_create(accelgpu_ctx **out, int device)
     if ((rc = allow_lds(speck::k_bigfft_rows<P16K>, P16K::LDS_BYTES))) return rc;
     if ((rc = reserve_hits(ctx, (size_t) 1 << 20))) return rc;
     select_slot(ctx, 0);
+    guard.c = nullptr;
     *out = ctx;
     return ACCELGPU_OK;
 }
@@ -877,11 +1014,66 @@ void accelgpu_destroy(accelgpu_ctx *ctx)
     if (ctx->opt.h_prob) (void) hipHostFree(ctx->opt.h_prob);
     if (ctx->opt.h_res) (void) hipHostFree(ctx->opt.h_res);
     if (ctx->opt.done) (void) hipEventDestroy(ctx->opt.done);
+    for (hipEvent_t e : ctx->own_ready)
+        if (e) (void) hipEventDestroy(e);
     if (ctx->copy_stream) (void) hipStreamDestroy(ctx->copy_stream);
     if (ctx->side_stream) (void) hipStreamDestroy(ctx->side_stream);
     if (ctx->opt_stream) (void) hipStreamDestroy(ctx->opt_stream);
     if (ctx->own_stream) (void) hipStreamDestroy(ctx->own_stream);
     delete ctx;
+}
+
+int accelgpu_set_tuning(accelgpu_ctx *ctx, const char *name, int value)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if (!name) {
+        set_error("accelgpu_set_tuning: null name");
+        return ACCELGPU_ERR_ARG;
+    }
+    if (ctx->inflight > 0) {
+        set_error("accelgpu_set_tuning: collect the launched trial(s) first");
+        return ACCELGPU_ERR_ARG;
+    }
+    if (!strcmp(name, "hits_cap")) {
+        // the device hit buffers, both of them, at exactly this size (tests of the regrow path)
+        if (value < 1) {
+            set_error("accelgpu_set_tuning: hits_cap must be positive");
+            return ACCELGPU_ERR_ARG;
+        }
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < 2; i++)
+            if ((rc = resize_slot(ctx, i, (size_t) value))) return rc;
+        select_slot(ctx, ctx->head);
+        return ACCELGPU_OK;
+    }
+    for (const TuneName &k : kTuneNames)
+        if (!strcmp(name, k.name)) {
+            ctx->tune.*(k.field) = value;
+            ctx->graph_stale = true;
+            return ACCELGPU_OK;
+        }
+    set_error("accelgpu_set_tuning: no knob named '%s'", name);
+    return ACCELGPU_ERR_ARG;
+}
+
+int accelgpu_get_tuning(accelgpu_ctx *ctx, const char *name, int *value)
+{
+    if (!ctx || !name || !value) {
+        set_error("accelgpu_get_tuning: null argument");
+        return ACCELGPU_ERR_ARG;
+    }
+    if (!strcmp(name, "hits_cap")) {
+        *value = (int) std::min<size_t>(std::min(ctx->slots[0].cap, ctx->slots[1].cap), 0x7FFFFFFF);
+        return ACCELGPU_OK;
+    }
+    for (const TuneName &k : kTuneNames)
+        if (!strcmp(name, k.name)) {
+            *value = ctx->tune.*(k.field);
+            return ACCELGPU_OK;
+        }
+    set_error("accelgpu_get_tuning: no knob named '%s'", name);
+    return ACCELGPU_ERR_ARG;
 }
 
 int accelgpu_set_stream(accelgpu_ctx *ctx, void *hip_stream)
@@ -898,6 +1090,11 @@ int accelgpu_synchronize(accelgpu_ctx *ctx)
     int rc = use(ctx);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int j = 0; j < accelgpu_ctx::kOwn; j++)
+        if (ctx->own_pending[j]) {
+            HIPCHK(hipEventSynchronize(ctx->own_ready[j]));
+            ctx->own_pending[j] = false;
+        }
     return ACCELGPU_OK;
 }
 
@@ -1003,6 +1200,60 @@ int accelgpu_load_fft(accelgpu_ctx *ctx, const float *host, int64_t numbins)
     HIPCHK(hipMemcpyAsync(ctx->d_own[j], host, (size_t) numbins * sizeof(c32),
                           hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream)); // the caller may free `host` on return
+    ctx->own_pending[j] = false;
+    ctx->cur_own = j;
+    ctx->d_fft = ctx->d_own[j];
+    ctx->numbins = numbins;
+    return ACCELGPU_OK;
+}
+
+int accelgpu_host_alloc(void **ptr, size_t bytes)
+{
+    if (!ptr || bytes == 0) {
+        set_error("accelgpu_host_alloc: null output or zero size");
+        return ACCELGPU_ERR_ARG;
+    }
+    *ptr = nullptr;
+    if (hipHostMalloc(ptr, bytes, hipHostMallocDefault) != hipSuccess) {
+        set_error("cannot page-lock %zu bytes of host memory", bytes);
+        return ACCELGPU_ERR_NOMEM;
+    }
+    return ACCELGPU_OK;
+}
+
+int accelgpu_host_free(void *ptr)
+{
+    if (ptr)
+        HIPCHK(hipHostFree(ptr));
+    return ACCELGPU_OK;
+}
+
+int accelgpu_load_fft_async(accelgpu_ctx *ctx, const float *host, int64_t numbins)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if (!host || numbins <= 0) {
+        set_error("accelgpu_load_fft_async: null spectrum or numbins <= 0");
+        return ACCELGPU_ERR_ARG;
+    }
+    // a pageable source would make the "asynchronous" copy a staged, blocking one
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, host) != hipSuccess || attr.type != hipMemoryTypeHost) {
+        (void) hipGetLastError();
+        set_error("accelgpu_load_fft_async: the spectrum must be in page-locked host memory "
+                  "(accelgpu_host_alloc); use accelgpu_load_fft for ordinary memory");
+        return ACCELGPU_ERR_ARG;
+    }
+    int j = 0;
+    if ((rc = pick_own(ctx, &j))) return rc;
+    if ((rc = dev_reserve(&ctx->d_own[j], &ctx->own_cap[j], (size_t) numbins, false, ctx->side_stream)))
+        return rc;
+    // always the side stream: the copy engine works beside whatever the search stream runs,
+    // and the launch that reads this buffer waits for own_ready[j] on the device
+    HIPCHK(hipMemcpyAsync(ctx->d_own[j], host, (size_t) numbins * sizeof(c32),
+                          hipMemcpyHostToDevice, ctx->side_stream));
+    HIPCHK(hipEventRecord(ctx->own_ready[j], ctx->side_stream));
+    ctx->own_pending[j] = true;
     ctx->cur_own = j;
     ctx->d_fft = ctx->d_own[j];
     ctx->numbins = numbins;
@@ -1287,6 +1538,7 @@ int accelgpu_search_plane(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hit
     const int si = ctx->head;
     select_slot(ctx, si);
     ctx->slots[si].prefetch = 0;
+    ctx->slots[si].serial = ctx->plane_serial; // searches the plane as it stands
     if ((rc = queue_search(ctx))) return rc;
     HIPCHK(hipEventRecord(ctx->slots[si].done, ctx->stream));
     return finish_search(ctx, si, hits, max_hits, n_hits);
@@ -1296,7 +1548,7 @@ int accelgpu_run_launch(accelgpu_ctx *ctx)
 {
     int rc = use(ctx);
     if (rc) return rc;
-    if ((rc = check_ready(ctx, true))) return rc;
+    if ((rc = check_ready(ctx, true, false))) return rc;
     if ((rc = need_plane(ctx))) return rc;
     if (ctx->inflight >= 2) {
         set_error("accelgpu_run_launch: two launches are already in flight; collect one first");
@@ -1308,21 +1560,25 @@ int accelgpu_run_launch(accelgpu_ctx *ctx)
     sl.prefetch = 0;
     sl.fft = ctx->d_fft;
     sl.numbins = ctx->numbins;
+    sl.serial = ++ctx->launch_serial;
     if (ctx->range_count > 0) {
+        if ((rc = spectrum_ready(ctx, ctx->stream))) return rc;
         if ((rc = queue_fill(ctx))) return rc;
+        ctx->plane_serial = sl.serial;
         // the copy stream takes over once this trial's last kernel is done, so the next
         // trial's kernels never queue behind PCIe transfers
         HIPCHK(hipMemsetAsync(ctx->d_count, 0, sizeof(unsigned int), ctx->stream));
         if ((rc = launch_harmsum<false>(ctx, ctx->setup.numharmstages,
                                         ctx->col0 + (int64_t) ctx->range_first * ACCELGPU_USELEN,
-                                        (int64_t) ctx->range_count * ACCELGPU_USELEN, nullptr, 0)))
+                                        (int64_t) ctx->range_count * ACCELGPU_USELEN, nullptr, 0,
+                                        slot_target(ctx))))
             return rc;
         HIPCHK(hipEventRecord(sl.kernels, ctx->stream));
         HIPCHK(hipStreamWaitEvent(ctx->copy_stream, sl.kernels, 0));
         HIPCHK(hipMemcpyAsync(sl.h_count, sl.d_count, sizeof(unsigned int), hipMemcpyDeviceToHost,
                               ctx->copy_stream));
         // speculative copy of the head of the hit buffer: usually all of them
-        const size_t pre = std::min<size_t>(ctx->hits_cap, 65536);
+        const size_t pre = std::min<size_t>(sl.cap, 65536);
         HIPCHK(hipMemcpyAsync(sl.h_hits, sl.d_hits, pre * sizeof(DevHit), hipMemcpyDeviceToHost,
                               ctx->copy_stream));
         sl.prefetch = pre;
@@ -1348,25 +1604,22 @@ int accelgpu_run_collect(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits
         return ACCELGPU_ERR_ARG;
     }
     const int si = ctx->head;
+    *n_hits = 0;
+    if (ctx->range_count == 0) {
+        HIPCHK(hipEventSynchronize(ctx->slots[si].done));
+    } else {
+        // The trial stays at the head of the queue until its hits have been handed over:
+        // after any failure (a caller's buffer too small: ACCELGPU_ERR_OVERFLOW with the
+        // count in *n_hits) the same call can simply be made again.
+        rc = finish_search(ctx, si, hits, max_hits, n_hits);
+        if (rc) return rc;
+    }
     ctx->head ^= 1;
     ctx->inflight--;
     ctx->collected.fft = ctx->slots[si].fft;
     ctx->collected.numbins = ctx->slots[si].numbins;
     ctx->collected.valid = true;
-    *n_hits = 0;
-    if (ctx->range_count == 0) {
-        HIPCHK(hipEventSynchronize(ctx->slots[si].done));
-        return ACCELGPU_OK;
-    }
-    rc = finish_search(ctx, si, hits, max_hits, n_hits);
-    if (rc == ACCELGPU_ERR_OVERFLOW && *n_hits > max_hits && (size_t) *n_hits <= ctx->hits_cap) {
-        // the caller's buffer was too small; the hits are still in the slot's pinned
-        // mirror, so let a following accelgpu_search_plane() (plane intact) or a
-        // larger collect retry succeed: put the slot back
-        ctx->head = si;
-        ctx->inflight++;
-    }
-    return rc;
+    return ACCELGPU_OK;
 }
 
 int accelgpu_run(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits, int64_t *n_hits)
@@ -1426,7 +1679,7 @@ int accelgpu_summed_block(accelgpu_ctx *ctx, int block, int stage, float *powers
     const size_t elems = (size_t) ctx->numz * ACCELGPU_USELEN;
     if ((rc = dev_reserve(&ctx->d_tmp, &ctx->tmp_cap, elems, false, ctx->stream))) return rc;
     rc = launch_harmsum<true>(ctx, ctx->setup.numharmstages, ctx->col0 + (int64_t) block * ACCELGPU_USELEN,
-                              ACCELGPU_USELEN, ctx->d_tmp, stage);
+                              ACCELGPU_USELEN, ctx->d_tmp, stage, slot_target(ctx));
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(powers, ctx->d_tmp, elems * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -111,3 +111,50 @@ def test_cfg4_full_size(gpu):
     setup, hits, cands = _check(gpu, 1 << 26, 64e-6, 300, 16,
                                 [(9.5e5 + 0.5, 290.0, 20.0), (3.1e7 + 0.25, -288.0, 20.0), (6.6e7, 10.0, 14.0)], 23)
     assert setup.num_search_blocks == 17965 and setup.plane_bytes > 161e9
+
+
+def _oracle_parity(gpu, oracle, name, N, max_hits):
+    """The whole search on the GPU against the whole search on the CPU oracle, same
+    spectrum, same flags: the main loop of src/accelsearch.c:165-218 with
+    search_ffdotpows (src/accel_utils.c:1259-1299) at every stage."""
+    import os
+    from oracle.compare import assert_same_search
+    fft, c = synth.config_fft(name, N=N)
+    threads = min(16, os.cpu_count() or 1)
+    s = oracle.Search(fft, N, c["dt"], c["zmax"], c["numharm"], fhi=1e9, nthreads=threads)
+    want_hits, want_cands = s.run(max_hits=max_hits)
+    s.close()                                   # the oracle's plane (GBs of host memory) goes first
+    setup = gpu.configure(fft.size, N, c["dt"], c["zmax"], c["numharm"], fhi=1e9)
+    gpu.load_fft(fft)
+    got_hits, got_cands, sig, added = gpu.search(max_hits=max_hits)
+    assert len(want_hits) > 1000
+    rel, edge_g, edge_w = assert_same_search(setup.powcut, got_hits, want_hits, min_matched=0.995)
+    if len(edge_g) == 0 and len(edge_w) == 0:
+        assert np.array_equal(got_cands["r"], want_cands["r"])
+        assert np.array_equal(got_cands["z"], want_cands["z"])
+        assert np.array_equal(got_cands["numharm"], want_cands["numharm"])
+        np.testing.assert_allclose(got_cands["power"], want_cands["power"], rtol=1e-3)
+        np.testing.assert_allclose(got_cands["sigma"], want_cands["sigma"], rtol=1e-3, atol=1e-3)
+    # the strongest candidates are far from any threshold: both sides must list them
+    top = np.argsort(-want_cands["sigma"])[:20]
+    gkey = {(float(r), float(z), int(n)): (p, sg) for r, z, n, p, sg in
+            zip(got_cands["r"], got_cands["z"], got_cands["numharm"], got_cands["power"], got_cands["sigma"])}
+    for w in want_cands[top]:
+        k = (float(w["r"]), float(w["z"]), int(w["numharm"]))
+        assert k in gkey, k
+        assert abs(gkey[k][0] - w["power"]) <= 1e-3 * w["power"]
+        assert abs(gkey[k][1] - w["sigma"]) <= 1e-3 * max(w["sigma"], 1.0)
+    return len(rel), len(edge_g), len(edge_w)
+
+
+def test_cfg2_full_size_against_oracle(gpu, oracle):
+    """The headline workload itself (2^23-point series, zmax 200, numharm 16)."""
+    matched, only_g, only_w = _oracle_parity(gpu, oracle, "cfg2", 1 << 23, 8_000_000)
+    print("cfg2 2^23: %d hits matched, %d GPU-only, %d oracle-only at a threshold" % (matched, only_g, only_w))
+
+
+def test_cfg5_reduced_against_oracle(gpu, oracle):
+    """zmax 1200, numharm 32 (16384-point transforms, 31 sub-harmonics) on a 2^21-point
+    series: the largest size of this configuration the CPU oracle does in well under a minute."""
+    matched, only_g, only_w = _oracle_parity(gpu, oracle, "cfg5", 1 << 21, 20_000_000)
+    print("cfg5 2^21: %d hits matched, %d GPU-only, %d oracle-only at a threshold" % (matched, only_g, only_w))

@@ -162,20 +162,10 @@ def test_harmonic_sum_and_threshold_bit_exact(gpu, oracle, name, N, zmax, numhar
     s.close()
 
 
-def _compare_lists(setup, got_hits, want_hits, tol_edge=PLANE_TOL * 4):
+def _compare_lists(setup, got_hits, want_hits):
     """Match hits by (stage, zind, rind); unmatched ones must sit at a threshold."""
-    powcut = np.array(list(setup.powcut), dtype=np.float64)
-    key = lambda st, z, r: (st.astype(np.int64) << 56) | (z.astype(np.int64) << 40) | r
-    kg = key(got_hits["stage"], got_hits["zind"], got_hits["rind"])
-    kw = key(np.log2(want_hits["numharm"]).astype(np.int64), want_hits["zind"], want_hits["rind"])
-    common, ig, iw = np.intersect1d(kg, kw, return_indices=True)
-    rel = np.abs(got_hits["power"][ig] - want_hits["power"][iw]) / want_hits["power"][iw]
-    only_g = np.setdiff1d(np.arange(len(kg)), ig)
-    only_w = np.setdiff1d(np.arange(len(kw)), iw)
-    edge_g = np.abs(got_hits["power"][only_g] / powcut[got_hits["stage"][only_g]] - 1.0)
-    st_w = np.log2(want_hits["numharm"][only_w]).astype(int)
-    edge_w = np.abs(want_hits["power"][only_w] / powcut[st_w] - 1.0)
-    return rel, edge_g, edge_w
+    from oracle.compare import compare_lists
+    return compare_lists(setup.powcut, got_hits, want_hits)
 
 
 @pytest.mark.parametrize("name,N,zmax,numharm", [("cfg1", 1 << 20, 0, 8), ("cfg2", 1 << 19, 200, 16),
