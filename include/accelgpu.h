@@ -392,6 +392,20 @@ int accelgpu_run_standard(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hit
  * [z][r], exactly the ffdotpows.powers matrix.  ref: subharm_ffdot_plane(1,1,
  * startr, startr+3734.5, ...), src/accel_utils.c:879-1056; *rlo_out = ffdot->rlo. */
 int accelgpu_fund_block(accelgpu_ctx *ctx, double startr, float *powers, int32_t *rlo_out);
+/* No counterpart in the reference.  For callers that cannot allocate device memory or
+ * wait on the host: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  accelgpu_fund_block() for 1..ACCELGPU_NOALLOC_MAX_BLOCKS blocks at
+ * once, startr[i] each, of the current spectrum: the powers go to the caller's DEVICE
+ * buffer, nblocks*numz*USELEN floats laid out [block][z][r]; rlo_out (host, optional)
+ * receives each block's rlo.  The block spectra and descriptors live in a fixed array in
+ * the library's device image (1 MiB + 512 B per GPU, held until the process ends), so the
+ * call makes no hipMalloc/hipFree and no host-device copy; its kernels are queued on the
+ * context's stream and it returns without waiting for them.  More blocks than the array
+ * holds is ACCELGPU_ERR_ARG.  Every context on a GPU shares that GPU's array: calls that
+ * overlap in time on one GPU race; calls on one stream are ordered and safe. */
+#define ACCELGPU_NOALLOC_MAX_BLOCKS 16
+int accelgpu_fund_blocks_noalloc(accelgpu_ctx *ctx, const double *startr, int32_t nblocks,
+                                 float *powers_dev, int32_t *rlo_out);
 /* The block at search index `block` after harmonic stage `stage` (0 = plain
  * fundamental), summed from the plane as it stands.  ref: the `fundamental`
  * matrix after the inmem_add_ffdotpows() calls of stage `stage`,

@@ -83,6 +83,7 @@ def load_library():
     L.accelgpu_set_tuning.argtypes = [vp, C.c_char_p, i]
     L.accelgpu_get_tuning.argtypes = [vp, C.c_char_p, C.POINTER(i)]
     L.accelgpu_load_dat.argtypes = [vp, vp, i64, i]
+    L.accelgpu_fund_blocks_noalloc.argtypes = [vp, C.POINTER(d), i, vp, C.POINTER(C.c_int32)]
     L.accelgpu_deredden.argtypes = [vp]
     L.accelgpu_rednoise.argtypes = [vp, i, i, d, d]
     L.accelgpu_get_fft.argtypes = [vp, vp, i64]
@@ -453,6 +454,15 @@ class AccelSearchGPU:
         rlo = C.c_int32(0)
         _check(self.L.accelgpu_fund_block(self._h, float(startr), _ptr(out), C.byref(rlo)))
         return out, rlo.value
+
+    def fund_blocks_noalloc(self, startrs, out_dev_ptr):
+        """Fundamental blocks at startrs into a caller's device buffer
+        ([len(startrs), numz, USELEN] float32) without allocating or waiting; returns
+        each block's rlo.  Synchronise the context before reading the buffer."""
+        sr = (C.c_double * len(startrs))(*[float(x) for x in startrs])
+        rlo = (C.c_int32 * len(startrs))()
+        _check(self.L.accelgpu_fund_blocks_noalloc(self._h, sr, len(startrs), C.c_void_p(out_dev_ptr), rlo))
+        return list(rlo)
 
     def summed_block(self, block, stage):
         out = np.empty((self.setup.numz, USELEN), dtype=np.float32)

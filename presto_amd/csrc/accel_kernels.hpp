@@ -924,6 +924,26 @@ __global__ __launch_bounds__(256) void k_block_threshold(const float *__restrict
 }
 
 
+// Block descriptors handed over as kernel arguments and written to device memory by the
+// kernel itself: no host-to-device copy, so nothing to stage and nothing to wait for.
+constexpr int DESC_MAX = 16;
+struct BlockDescArgs {
+    int64_t lobin[DESC_MAX], col[DESC_MAX];
+    int numdata[DESC_MAX], ncols[DESC_MAX];
+};
+__global__ void k_write_desc(BlockDescArgs a, int n, int64_t *__restrict__ lobin,
+                             int64_t *__restrict__ col, int *__restrict__ numdata,
+                             int *__restrict__ ncols)
+{
+    const int i = threadIdx.x;
+    if (i < n) {
+        lobin[i] = a.lobin[i];
+        col[i] = a.col[i];
+        numdata[i] = a.numdata[i];
+        ncols[i] = a.ncols[i];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Standard (not in-memory) mode, batched over nb blocks.  Block matrices are
 // laid out [z][block][column] so that one correlate launch fills all blocks.

@@ -19,6 +19,7 @@
 #include <chrono>
 #include <deque>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "accel_host.hpp"
@@ -69,6 +70,21 @@ template <class T> struct DevTemp {
 };
 
 } // namespace
+
+// Working memory of accelgpu_fund_blocks_noalloc(), the entry point for callers that
+// cannot allocate: block descriptors and the block spectra of up to kNoAllocBlocks blocks
+// of the longest plan.  Every GPU the library runs on holds its own copy of this array,
+// at its own address, until the process ends.  Host code never uses the array's name as
+// an address: accelgpu_create() asks the runtime for the device address once per device
+// (with that device current) and keeps it in g_scratch_ptr[device].
+constexpr int kNoAllocBlocks = accelk::DESC_MAX;
+constexpr size_t kScratchDescBytes = 512;                                  // lobin, col, numdata, ncols
+constexpr size_t kScratchBlockfftBytes = (size_t) kNoAllocBlocks * 8192 * sizeof(accelk::c32);
+constexpr size_t kScratchBytes = kScratchDescBytes + kScratchBlockfftBytes; // 1 MiB + 512 B
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+constexpr int kMaxDevices = 64;
+static unsigned char *g_scratch_ptr[kMaxDevices];
+static std::mutex g_scratch_mutex;
 
 // Launch-shape knobs.  Defaults are the measured optima; accelgpu_create() reads the
 // ACCELGPU_* environment overrides once, accelgpu_set_tuning() changes one by name
@@ -921,6 +937,20 @@ int accelgpu_create(accelgpu_ctx **out, int device)
         return ACCELGPU_ERR_ARG;
     }
     HIPCHK(hipSetDevice(device));
+    if (device >= kMaxDevices) {
+        set_error("accelgpu_create: device index %d beyond the %d this library keeps state for", device,
+                  kMaxDevices);
+        return ACCELGPU_ERR_ARG;
+    }
+    {
+        // once per device, with that device current: the address of this device's copy
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[device]) {
+            unsigned char *p = nullptr;
+            HIPCHK(hipGetSymbolAddress((void **) &p, HIP_SYMBOL(scratch)));
+            g_scratch_ptr[device] = p;
+        }
+    }
     // released on every early return below; handed to the caller at the end
     struct Guard {
         accelgpu_ctx *c;
@@ -1663,6 +1693,73 @@ int accelgpu_fund_block(accelgpu_ctx *ctx, double startr, float *powers, int32_t
     if (rlo_out)
         *rlo_out = d.rlo;
     return ACCELGPU_OK;
+}
+
+// accelgpu_fund_block() for callers that cannot allocate: up to kNoAllocBlocks blocks per
+// call, block spectra and descriptors in this device's `scratch` array, powers into the
+// caller's device buffer.  No hipMalloc/hipFree, no host-device copies, no host wait: the
+// work is queued on the context's stream.  Calls on one GPU share that GPU's array, so
+// calls that overlap in time there (two contexts, two streams) race.
+int accelgpu_fund_blocks_noalloc(accelgpu_ctx *ctx, const double *startr, int32_t nblocks,
+                                 float *powers_dev, int32_t *rlo_out)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if ((rc = check_ready(ctx, true))) return rc;
+    if (!startr || !powers_dev || nblocks < 1) {
+        set_error("accelgpu_fund_blocks_noalloc: null argument or no blocks");
+        return ACCELGPU_ERR_ARG;
+    }
+    if (nblocks > kNoAllocBlocks) {
+        set_error("accelgpu_fund_blocks_noalloc: %d blocks in one call, the fixed working memory holds %d",
+                  nblocks, kNoAllocBlocks);
+        return ACCELGPU_ERR_ARG;
+    }
+    static_assert(kScratchBlockfftBytes >= (size_t) kNoAllocBlocks * (16384 / 2) * sizeof(c32),
+                  "working memory sized for the longest plan");
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, powers_dev) != hipSuccess || attr.type != hipMemoryTypeDevice) {
+        (void) hipGetLastError();
+        set_error("accelgpu_fund_blocks_noalloc: the output must be device memory");
+        return ACCELGPU_ERR_ARG;
+    }
+    unsigned char *base = g_scratch_ptr[ctx->device];
+    if (!base) {
+        set_error("accelgpu_fund_blocks_noalloc: no working memory on device %d", ctx->device);
+        return ACCELGPU_ERR_HIP;
+    }
+    int64_t *d_lobin = reinterpret_cast<int64_t *>(base);
+    int64_t *d_col = d_lobin + kNoAllocBlocks;
+    int *d_numdata = reinterpret_cast<int *>(d_col + kNoAllocBlocks);
+    int *d_ncols = d_numdata + kNoAllocBlocks;
+    c32 *d_blockfft = reinterpret_cast<c32 *>(base + kScratchDescBytes);
+    static_assert(kNoAllocBlocks * (2 * sizeof(int64_t) + 2 * sizeof(int)) <= kScratchDescBytes, "descriptors fit");
+
+    // output layout [block][z][column]: row stride USELEN, block b starts numz rows further on
+    accelk::BlockDescArgs a{};
+    for (int b = 0; b < nblocks; b++) {
+        const BlockDesc d = describe_block(startr[b], ctx->halfwidth);
+        if (d.numdata > ctx->fftlen / 2) {
+            set_error("block window of %d bins exceeds fftlen/2 = %d", d.numdata, ctx->fftlen / 2);
+            return ACCELGPU_ERR_ARG;
+        }
+        a.lobin[b] = d.lobin;
+        a.col[b] = (int64_t) b * ctx->numz * ACCELGPU_USELEN;
+        a.numdata[b] = d.numdata;
+        a.ncols[b] = ACCELGPU_USELEN;
+        if (rlo_out)
+            rlo_out[b] = d.rlo;
+    }
+    hipLaunchKernelGGL(accelk::k_write_desc, dim3(1), dim3(64), 0, ctx->stream, a, (int) nblocks, d_lobin,
+                       d_col, d_numdata, d_ncols);
+    HIPCHK(hipGetLastError());
+    const bool prof = ctx->profiling; // the timing brackets create events
+    ctx->profiling = false;
+    rc = launch_block_prep(ctx, nblocks, d_lobin, d_numdata, d_blockfft);
+    if (!rc)
+        rc = launch_correlate(ctx, nblocks, d_blockfft, d_col, d_ncols, powers_dev, ACCELGPU_USELEN);
+    ctx->profiling = prof;
+    return rc;
 }
 
 int accelgpu_summed_block(accelgpu_ctx *ctx, int block, int stage, float *powers)
