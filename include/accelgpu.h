@@ -173,6 +173,11 @@ int accelgpu_load_dat(accelgpu_ctx *ctx, const float *series, int64_t n, int der
 /* deredden() on the current spectrum in place (it must be library-owned:
  * accelgpu_load_fft or accelgpu_load_dat).  ref: src/accel_utils.c:1301-1374. */
 int accelgpu_deredden(accelgpu_ctx *ctx);
+/* Overwrites bin 0 (the packed DC and Nyquist terms) of the current, library-owned
+ * spectrum.  A host that searches a time series without -photon calls it with (1, 1)
+ * after accelgpu_load_dat(.., deredden), as the reference does so that the lowest
+ * blocks' windows do not pick up the DC term.  ref: src/accel_utils.c:1553-1556. */
+int accelgpu_set_bin0(accelgpu_ctx *ctx, float re, float im);
 /* The stand-alone rednoise filter on the current spectrum in place: median
  * blocks of startwidth*ln(bin) bins up to frequency endfreq (Hz), endwidth
  * beyond; T = N*dt in seconds.  Reproduces the program's output file bin for
@@ -234,7 +239,9 @@ int accelgpu_fill_plane(accelgpu_ctx *ctx);
 int accelgpu_search_plane(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits,
                           int64_t *n_hits);
 
-/* accelgpu_fill_plane() followed by accelgpu_search_plane(). */
+/* accelgpu_fill_plane() followed by accelgpu_search_plane().  With a buffer that is too
+ * small it returns ACCELGPU_ERR_OVERFLOW and the count in *n_hits, and nothing stays
+ * queued: call it again with room for that many. */
 int accelgpu_run(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits, int64_t *n_hits);
 
 /* Asynchronous halves of accelgpu_run() for pipelined batches: _launch queues

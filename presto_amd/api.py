@@ -85,6 +85,7 @@ def load_library():
     L.accelgpu_load_dat.argtypes = [vp, vp, i64, i]
     L.accelgpu_fund_blocks_noalloc.argtypes = [vp, C.POINTER(d), i, vp, C.POINTER(C.c_int32)]
     L.accelgpu_deredden.argtypes = [vp]
+    L.accelgpu_set_bin0.argtypes = [vp, f, f]
     L.accelgpu_rednoise.argtypes = [vp, i, i, d, d]
     L.accelgpu_get_fft.argtypes = [vp, vp, i64]
     L.accelgpu_zapbirds.argtypes = [vp, vp, vp, C.c_int32]
@@ -302,6 +303,11 @@ class AccelSearchGPU:
         self._numbins = a.size // 2
         return self._numbins
 
+    def set_bin0(self, re, im):
+        """Overwrite bin 0 of the current spectrum (the reference sets (1, 1) for
+        time-series input without -photon, src/accel_utils.c:1553-1556)."""
+        _check(self.L.accelgpu_set_bin0(self._h, float(re), float(im)))
+
     def deredden(self):
         _check(self.L.accelgpu_deredden(self._h))
 
@@ -376,6 +382,11 @@ class AccelSearchGPU:
     def run(self, max_hits=1 << 20):
         self.run_launch()
         return self.run_collect(max_hits)
+
+    def run_one_call(self, max_hits=1 << 20):
+        """accelgpu_run() itself (fill + search in one C call, repeated from scratch with a
+        larger buffer when the hits do not fit)."""
+        return self._hits_call(self.L.accelgpu_run, max_hits)
 
     def run_launch(self):
         _check(self.L.accelgpu_run_launch(self._h))

@@ -43,27 +43,32 @@ def cands_to_records(trial, cands):
     return rec
 
 
-def allgather_records(records, device=None):
-    """All-gather of variable-length [n, 6] float64 record arrays over the default
-    torch.distributed group: counts first, then zero-padded fixed-size buffers.
-    Returns the concatenation in rank order (identical on every rank)."""
+def allgather_rows(rows, device=None):
+    """All-gather of variable-length [n, k] float64 arrays (same k on every rank) over
+    the default torch.distributed group: counts first, then zero-padded fixed-size
+    buffers.  Returns the concatenation in rank order (identical on every rank)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
     dev = device if device is not None else torch.device("cpu")
-    records = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, len(REC_FIELDS))
-    cnt = torch.tensor([records.shape[0]], dtype=torch.int64, device=dev)
+    rows = np.ascontiguousarray(rows, dtype=np.float64)
+    ncol = rows.shape[1]
+    cnt = torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev)
     cnts = [torch.zeros_like(cnt) for _ in range(world)]
     dist.all_gather(cnts, cnt)
     counts = [int(c.item()) for c in cnts]
-    mx = max(max(counts), 1)
-    buf = torch.zeros((mx, len(REC_FIELDS)), dtype=torch.float64, device=dev)
-    if records.shape[0]:
-        buf[:records.shape[0]] = torch.from_numpy(records).to(dev)
+    buf = torch.zeros((max(max(counts), 1), ncol), dtype=torch.float64, device=dev)
+    if rows.shape[0]:
+        buf[:rows.shape[0]] = torch.from_numpy(rows).to(dev)
     bufs = [torch.zeros_like(buf) for _ in range(world)]
     dist.all_gather(bufs, buf)
-    parts = [b[:n].cpu().numpy() for b, n in zip(bufs, counts)]
-    return np.concatenate(parts, axis=0) if parts else np.zeros((0, len(REC_FIELDS)))
+    return np.concatenate([b[:n].cpu().numpy() for b, n in zip(bufs, counts)], axis=0)
+
+
+def allgather_records(records, device=None):
+    """The candidate records ([n, 6], see REC_FIELDS) of every rank, in rank order."""
+    records = np.asarray(records, dtype=np.float64).reshape(-1, len(REC_FIELDS))
+    return allgather_rows(records, device)
 
 
 def merge_sorted(records):
@@ -114,25 +119,7 @@ def search_long_series(gpu, rank, world, max_hits=1 << 22, gather=None):
     if gather is None:
         import torch
         dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
-        allrec = _allgather_generic(rec, dev)
+        allrec = allgather_rows(rec, dev)
     else:
         allrec = gather(rec)
     return reference_order(records_to_hits(allrec, hits.dtype))
-
-
-def _allgather_generic(rec, device):
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size()
-    dev = device if device is not None else torch.device("cpu")
-    ncol = rec.shape[1]
-    cnt = torch.tensor([rec.shape[0]], dtype=torch.int64, device=dev)
-    cnts = [torch.zeros_like(cnt) for _ in range(world)]
-    dist.all_gather(cnts, cnt)
-    counts = [int(c.item()) for c in cnts]
-    buf = torch.zeros((max(max(counts), 1), ncol), dtype=torch.float64, device=dev)
-    if rec.shape[0]:
-        buf[:rec.shape[0]] = torch.from_numpy(np.ascontiguousarray(rec)).to(dev)
-    bufs = [torch.zeros_like(buf) for _ in range(world)]
-    dist.all_gather(bufs, buf)
-    return np.concatenate([b[:n].cpu().numpy() for b, n in zip(bufs, counts)], axis=0)

@@ -1656,7 +1656,18 @@ int accelgpu_run(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits, int64_
 {
     int rc = accelgpu_run_launch(ctx);
     if (rc) return rc;
-    return accelgpu_run_collect(ctx, hits, max_hits, n_hits);
+    rc = accelgpu_run_collect(ctx, hits, max_hits, n_hits);
+    if (rc && ctx->inflight > 0) {
+        // This call is the whole search or nothing: a trial whose hits could not be handed
+        // over (caller's buffer too small, *n_hits says how many) does not stay queued, so
+        // that calling accelgpu_run() again with a larger buffer starts from a clean queue.
+        // It is the most recent launch: the one at the tail.
+        (void) hipStreamSynchronize(ctx->stream);
+        (void) hipStreamSynchronize(ctx->copy_stream);
+        ctx->tail ^= 1;
+        ctx->inflight--;
+    }
+    return rc;
 }
 
 int accelgpu_fund_block(accelgpu_ctx *ctx, double startr, float *powers, int32_t *rlo_out)

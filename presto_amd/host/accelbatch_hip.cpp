@@ -65,6 +65,8 @@ struct Trial {
     int64_t numbins = 0;
     std::vector<float> data;     // packed spectrum (2*numbins floats) or the time series
     accelgpu_setup setup{};
+    int name_zmax = 0;           // -zmax as given: the reference names its files before it rounds zmax up
+                                 // to an even number (src/accel_utils.c:1492-1494, then :1526)
     int64_t nopt = 0;            // candidates handed to the optimisation
     std::vector<accelgpu_cand> kept;
 };
@@ -179,8 +181,11 @@ void stage_trial(accelgpu_ctx *gpu, Trial &t, const Options &o, Geometry &geo, a
         geo.dt = t.dt;
     }
     t.setup = su;
+    t.name_zmax = o.zmax;
     if (t.dat_input) {
         if (accelgpu_load_dat(gpu, t.data.data(), (int64_t) t.data.size(), 1)) die("accelgpu_load_dat");
+        // no -photon here: bin 0 becomes (1, 1) as in src/accel_utils.c:1553-1556
+        if (accelgpu_set_bin0(gpu, 1.0f, 1.0f)) die("accelgpu_set_bin0");
     } else if (accelgpu_load_fft(gpu, t.data.data(), t.numbins)) {
         die("accelgpu_load_fft");
     }
@@ -229,7 +234,7 @@ void collect_trial(accelgpu_ctx *gpu, Trial &t, const Options &o, std::vector<ac
                                    added.data()))
         die("accelgpu_replay_candidates");
     if (!t.dat_input) { // the work file of the search (src/accel_utils.c:1290-1294)
-        const std::string work = t.root + "_ACCEL_" + std::to_string(su.zmax) + ".txtcand";
+        const std::string work = t.root + "_ACCEL_" + std::to_string(t.name_zmax) + ".txtcand";
         FILE *w = fopen(work.c_str(), "w");
         if (!w) {
             perror(work.c_str());
@@ -265,7 +270,7 @@ void write_trial(accelgpu_ctx *gpu, Trial &t)
         return;
     std::vector<accelgpu_optcand> opt((size_t) t.nopt);
     if (accelgpu_optimize_collect(gpu, opt.data(), t.nopt)) die("accelgpu_optimize_collect");
-    const std::string accelnm = t.root + "_ACCEL_" + std::to_string(t.setup.zmax);
+    const std::string accelnm = t.root + "_ACCEL_" + std::to_string(t.name_zmax);
     if (accelgpu_write_accel_files(&t.setup, opt.data(), t.nopt, 0.f, accelnm.c_str(), (accelnm + ".cand").c_str(),
                                    t.inftext.c_str()))
         die("accelgpu_write_accel_files");

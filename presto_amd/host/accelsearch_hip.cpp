@@ -211,6 +211,9 @@ int main(int argc, char **argv)
         // The reference reads the photon count from bin 0 after de-reddening has
         // set it to 1 (src/accel_utils.c:1313, 1531-1533): so does this.
         if (photon) nph = 1.0f;
+        // without -photon bin 0 becomes (1, 1), so that the lowest blocks' windows do not
+        // pick up the DC term (src/accel_utils.c:1553-1556)
+        else if (accelgpu_set_bin0(gpu, 1.0f, 1.0f)) die("accelgpu_set_bin0");
     } else {
         if (accelgpu_load_fft(gpu, fft.data(), numbins)) die("accelgpu_load_fft");
         if (photon && lobin == 0) nph = fft[0];
@@ -242,7 +245,9 @@ int main(int argc, char **argv)
         die("accelgpu_replay_candidates");
 
     char work[4096];
-    snprintf(work, sizeof(work), "%s_ACCEL_%d.txtcand", root.c_str(), su.zmax);
+    snprintf(work, sizeof(work), "%s_ACCEL_%d.txtcand", root.c_str(), zmax); // as given: the reference names
+                                                                                // its files before it rounds zmax up
+                                                                                // (src/accel_utils.c:1492-1494, 1526)
     FILE *w = dat_input ? nullptr : fopen(work, "w");
     if (!w && !dat_input) {
         perror(work);
@@ -280,8 +285,8 @@ int main(int argc, char **argv)
             fclose(fi);
         }
         char accelnm[4096], candnm[4096];
-        snprintf(accelnm, sizeof(accelnm), "%s_ACCEL_%d", root.c_str(), su.zmax);
-        snprintf(candnm, sizeof(candnm), "%s_ACCEL_%d.cand", root.c_str(), su.zmax);
+        snprintf(accelnm, sizeof(accelnm), "%s_ACCEL_%d", root.c_str(), zmax);
+        snprintf(candnm, sizeof(candnm), "%s_ACCEL_%d.cand", root.c_str(), zmax);
         if (accelgpu_write_accel_files(&su, opt.data(), ncands, nph, accelnm, candnm, inftext.c_str()))
             die("accelgpu_write_accel_files");
         printf("Optimized %lld candidates; results in '%s' and '%s'.\n", (long long) ncands, accelnm, candnm);

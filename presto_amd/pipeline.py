@@ -102,6 +102,7 @@ def stage_trial(gpu, t, opts, state):
     with _timed("upload+prepare"):
         if dat_input:
             gpu.load_dat(t.data, deredden=True)
+            gpu.set_bin0(1.0, 1.0)          # no -photon here (src/accel_utils.c:1553-1556)
         else:
             gpu.load_fft(t.data)
         t.data = None
@@ -124,7 +125,7 @@ def collect_trial(gpu, t, opts):
         hits = gpu.run_collect(max_hits=1 << 18)
     with _timed("replay"):
         cands, sig, added = api.replay_candidates(setup, hits)
-    accelnm = "%s_ACCEL_%d" % (t.root, setup.zmax)
+    accelnm = "%s_ACCEL_%d" % (t.root, opts.zmax)    # as given: named before zmax is rounded up (src/accel_utils.c:1492-1494, 1526)
     if t.ext == ".fft":                     # the work file of the search (src/accel_utils.c:1291-1294)
         with _timed("txtcand"):
             sel = added != 0
@@ -149,7 +150,7 @@ def write_trial(gpu, t, opts, writer=None):
     a `writer` executor the files are written there and a future is returned."""
     from . import api
     setup = t.setup
-    accelnm = "%s_ACCEL_%d" % (t.root, setup.zmax)
+    accelnm = "%s_ACCEL_%d" % (t.root, opts.zmax)    # as given: named before zmax is rounded up (src/accel_utils.c:1492-1494, 1526)
     opt = None
     if t.nopt:
         with _timed("optimize wait"):
@@ -310,13 +311,13 @@ def run(files, opts, rank=0, world=1, device=0, gather=None):
         secs.append(dt_s)
     gpu.close()
     mine_rec = np.concatenate(recs) if recs else np.zeros((0, len(SIFT_FIELDS) + MAX_HARM))
-    allrec = mine_rec if world == 1 else (gather or batch._allgather_generic)(mine_rec, None)
+    allrec = mine_rec if world == 1 else (gather or batch.allgather_rows)(mine_rec, None)
     if rank != 0:
         return None, secs
     for i, f in enumerate(files):
         N, dt = read_inf(os.path.splitext(f)[0])
         Ts[i] = N * dt
-    names = ["%s_ACCEL_%d" % (os.path.splitext(f)[0], opts.zmax + opts.zmax % 2) for f in files]
+    names = ["%s_ACCEL_%d" % (os.path.splitext(f)[0], opts.zmax) for f in files]
     order = np.lexsort((allrec[:, 1], allrec[:, 0]))          # by file, then candidate number
     cl = records_to_candlist(allrec[order], names, Ts)
     dmstrs = []
@@ -365,7 +366,7 @@ def main(argv=None):
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
         dist.init_process_group("nccl", device_id=dev)
-        gather = lambda rec, _d: batch._allgather_generic(rec, dev)   # noqa: E731
+        gather = lambda rec, _d: batch.allgather_rows(rec, dev)   # noqa: E731
     t0 = time.perf_counter()
     cl, secs = run(sorted(opts.files), opts, rank, world, local, gather)
     if rank == 0:

@@ -132,3 +132,40 @@ def test_reload_keeps_the_spectrum_of_a_queued_optimisation(gpu):
     h2, k2, o2 = _plain(gpu, setup, specs[2])
     hits = gpu.run()
     assert np.array_equal(hits, h2)
+
+
+def test_device_hit_buffer_overflow_with_a_later_trial_queued(gpu):
+    """A trial with more hits than the device hit buffer holds, collected after the next
+    trial has been launched (which has overwritten the plane): the collect re-runs that
+    trial on its own spectrum into a larger buffer, and both trials come back exactly as
+    a plain one-after-the-other sequence returns them; so does a too-small caller buffer."""
+    specs = _spectra()[:3]
+    setup = gpu.configure(N // 2, N, DT, ZMAX, NH, fhi=4000.0)
+    want = []
+    for s in specs:
+        gpu.load_fft(s)
+        want.append(gpu.run())
+    assert min(len(w) for w in want) > 64
+    try:
+        gpu.set_tuning("hits_cap", 64)
+        assert gpu.get_tuning("hits_cap") == 64
+        gpu.load_fft(specs[0])
+        gpu.run_launch()
+        gpu.load_fft(specs[1])
+        gpu.run_launch()
+        got0 = gpu.run_collect(max_hits=8)       # device overflow and caller overflow at once
+        gpu.load_fft(specs[2])
+        gpu.run_launch()
+        got1 = gpu.run_collect()
+        got2 = gpu.run_collect()
+        for g, w in zip((got0, got1, got2), want):
+            assert np.array_equal(g, w)
+        with pytest.raises(pa.AccelGPUError, match="nothing launched"):
+            gpu.run_collect()
+        # the whole-search call with a caller buffer that is too small leaves nothing queued
+        gpu.load_fft(specs[0])
+        assert np.array_equal(gpu.run_one_call(max_hits=4), want[0])
+        with pytest.raises(pa.AccelGPUError, match="nothing launched"):
+            gpu.run_collect()
+    finally:
+        gpu.set_tuning("hits_cap", 1 << 20)

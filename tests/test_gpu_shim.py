@@ -56,14 +56,14 @@ def test_command_line_front_end(tmp_path):
     exe = os.path.join(ROOT, "presto_amd", "host", "accelsearch_hip")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.dirname(exe), "-s"])
-    N, dt, zmax, numharm = 1 << 18, 5e-4, 51, 4          # odd zmax: rounded up to 52 like the reference
+    N, dt, zmax, numharm = 1 << 18, 5e-4, 51, 4          # odd zmax: searched as 52, files named 51 (src/accel_utils.c:1492-1494 before :1526)
     fft = synth.make_fft(N, dt, [dict(f=77.7, z=-31.0, amp=0.3, duty=0.05)], seed=8)
     root = str(tmp_path / "trial_DM12.30")
     synth.write_fft(root, fft, N, dt)
     out = subprocess.check_output([exe, "-zmax", str(zmax), "-numharm", str(numharm), "-flo", "2.0",
                                    "-fhi", "900", "-inmem", root + ".fft"], timeout=170).decode()
     assert "FFT length = 8192" in out and "Searched the following approx numbers" in out
-    lines = open(root + "_ACCEL_52.txtcand").read().splitlines()
+    lines = open(root + "_ACCEL_51.txtcand").read().splitlines()
     g = pa.AccelSearchGPU(0)
     setup = g.configure(fft.size, N, dt, zmax, numharm, flo=2.0, fhi=900.0)
     g.load_fft(fft)

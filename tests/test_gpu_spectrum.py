@@ -104,10 +104,17 @@ def test_dat_input_end_to_end(gpu, oracle):
     n = 1 << 19
     x = _series(n, 9, red=0.02)
     spec = oracle.deredden(oracle.realfft(x))
+    spec[0] = 1.0 + 1.0j          # time-series input without -photon (src/accel_utils.c:1553-1556)
     s = oracle.Search(spec, n, 1e-3, 20, 8, fhi=1e9, nthreads=8)
     ohits, ocands = s.run()
     gpu.configure(n // 2, n, 1e-3, 20, 8, fhi=1e9)
     gpu.load_dat(x, deredden=True)
+    gpu.set_bin0(1.0, 1.0)
+    assert gpu.get_fft(n // 2)[0] == np.complex64(1.0 + 1.0j)
+    # the pre-population block at r = 8 has bin 0 inside its window
+    want0, _ = s.fund_block(8.0)
+    got0, _ = gpu.subharm_ffdot_plane(8.0)
+    assert np.abs(got0 - want0).max() <= 1e-3 * want0.max()
     ghits, gcands, sig, added = gpu.search()
     assert len(ocands) > 0
     ok = {(int(h["block"]), int(np.log2(h["numharm"])), int(h["zind"]), int(h["rind"])): float(h["power"]) for h in ohits}

@@ -149,7 +149,7 @@ def _sift_worker(rank, world, port, q):
         lists[i] = sifting.Candlist(cands)
     mine = batch.shard_trials(4, rank, world)
     rec = np.concatenate([pipeline.candlist_to_records(lists[i], i) for i in mine])
-    allrec = batch._allgather_generic(rec, None)
+    allrec = batch.allgather_rows(rec, None)
     if rank == 0:
         names = ["b_DM%.2f_ACCEL_50" % dm for dm in (0.0, 10.0, 20.0, 30.0)]
         order = np.lexsort((allrec[:, 1], allrec[:, 0]))

@@ -4,9 +4,10 @@ Pinned against the reference's own code (the five self-contained files built
 unmodified into oracle/_ref/libprestoref.so): Fresnel integrals, the quickselect
 median, the chi^2 / normal routines behind power_for_sigma and candidate_sigma,
 and the downhill simplex of the candidate optimisation.  Pinned against mathematics: the z-response versus quadrature
-of its defining integral, the FFT versus a double-precision DFT.  Pinned against
-numbers recorded from a run of the reference program (tests/golden/setup_tables.json):
-half-widths, FFT lengths, block counts, numindep and powcut tables.
+of its defining integral, the FFT versus a double-precision DFT.  Checked against an
+independent evaluation of the reference's set-up formulas (tests/golden/setup_tables.json,
+computed with SciPy, not output of the reference program): half-widths, FFT lengths,
+block counts, numindep and powcut tables.
 """
 import ctypes as C
 import json
