@@ -760,6 +760,28 @@ int queue_fill(accelgpu_ctx *ctx)
                             ctx->d_blk_ncols, ctx->d_plane, ctx->setup.rlen);
 }
 
+// Plane generation and harmonic sum of one whole trial, chunk by chunk in ascending r: the
+// fundamental of a chunk of search blocks is generated and summed right away, while it is
+// still in the caches (a sub-harmonic's source column lies below the column it is added
+// to, so it has been written by this or an earlier chunk).  Only for the whole block grid.
+int queue_fill_and_sum_chunked(accelgpu_ctx *ctx, int chunk_blocks, const HitTarget &out)
+{
+    int rc = launch_block_prep(ctx, ctx->nblk, ctx->d_blk_lobin, ctx->d_blk_numdata, ctx->d_blockfft);
+    if (rc) return rc;
+    const size_t nf = (size_t) ctx->fftlen / 2;
+    for (int s0 = 0; s0 < ctx->nsearch; s0 += chunk_blocks) {
+        const int s1 = std::min(s0 + chunk_blocks, ctx->nsearch);
+        const int b0 = s0 == 0 ? 0 : ctx->nprepop + s0, b1 = ctx->nprepop + s1; // pre-population blocks go first
+        if ((rc = launch_correlate(ctx, b1 - b0, ctx->d_blockfft + (size_t) b0 * nf, ctx->d_blk_col + b0,
+                                   ctx->d_blk_ncols + b0, ctx->d_plane, ctx->setup.rlen)))
+            return rc;
+        if ((rc = launch_harmsum<false>(ctx, ctx->setup.numharmstages, ctx->col0 + (int64_t) s0 * ACCELGPU_USELEN,
+                                        (int64_t) (s1 - s0) * ACCELGPU_USELEN, nullptr, 0, out)))
+            return rc;
+    }
+    return ACCELGPU_OK;
+}
+
 int queue_search(accelgpu_ctx *ctx)
 {
     HIPCHK(hipMemsetAsync(ctx->d_count, 0, sizeof(unsigned int), ctx->stream));
@@ -1593,16 +1615,22 @@ int accelgpu_run_launch(accelgpu_ctx *ctx)
     sl.serial = ++ctx->launch_serial;
     if (ctx->range_count > 0) {
         if ((rc = spectrum_ready(ctx, ctx->stream))) return rc;
-        if ((rc = queue_fill(ctx))) return rc;
-        ctx->plane_serial = sl.serial;
+        HIPCHK(hipMemsetAsync(ctx->d_count, 0, sizeof(unsigned int), ctx->stream));
+        const bool whole_grid = ctx->nblk_active == ctx->nblk && ctx->range_first == 0 && ctx->range_count == ctx->nsearch;
+        if (ctx->tune.hs_chunk_blocks > 0 && whole_grid) {
+            if ((rc = queue_fill_and_sum_chunked(ctx, ctx->tune.hs_chunk_blocks, slot_target(ctx)))) return rc;
+            ctx->plane_serial = sl.serial;
+        } else {
+            if ((rc = queue_fill(ctx))) return rc;
+            ctx->plane_serial = sl.serial;
+            if ((rc = launch_harmsum<false>(ctx, ctx->setup.numharmstages,
+                                            ctx->col0 + (int64_t) ctx->range_first * ACCELGPU_USELEN,
+                                            (int64_t) ctx->range_count * ACCELGPU_USELEN, nullptr, 0,
+                                            slot_target(ctx))))
+                return rc;
+        }
         // the copy stream takes over once this trial's last kernel is done, so the next
         // trial's kernels never queue behind PCIe transfers
-        HIPCHK(hipMemsetAsync(ctx->d_count, 0, sizeof(unsigned int), ctx->stream));
-        if ((rc = launch_harmsum<false>(ctx, ctx->setup.numharmstages,
-                                        ctx->col0 + (int64_t) ctx->range_first * ACCELGPU_USELEN,
-                                        (int64_t) ctx->range_count * ACCELGPU_USELEN, nullptr, 0,
-                                        slot_target(ctx))))
-            return rc;
         HIPCHK(hipEventRecord(sl.kernels, ctx->stream));
         HIPCHK(hipStreamWaitEvent(ctx->copy_stream, sl.kernels, 0));
         HIPCHK(hipMemcpyAsync(sl.h_count, sl.d_count, sizeof(unsigned int), hipMemcpyDeviceToHost,
