@@ -99,30 +99,61 @@ static double chi2_logp(double chi2, int dof)
                 2.7777777777777777777778e-3) * y + 8.3333333333333333333333e-2) / a;
         return lig - lg;
     }
-    return std::log(chi2_sf_even(chi2, dof));
+    // log(exp(-h) * sum) with the exponential taken analytically: one libm call instead of
+    // two, and no underflow for large h
+    const int k = dof / 2;
+    const double h = 0.5 * chi2;
+    double term = 1.0, sum = 1.0;
+    for (int j = 1; j < k; j++) {
+        term *= h / j;
+        sum += term;
+    }
+    return std::log(sum) - h;
 }
 
 static double norm_sf(double x) { return 0.5 * std::erfc(x / M_SQRT2); }
 
-static double norm_isf(double q) // 0 < q < 1
+// Upper-tail quantile of the normal distribution from log q, 0 < q <= 1/2: Wichura's
+// rational approximations (Applied Statistics algorithm AS 241, routine PPND16; relative
+// error below 1e-15, i.e. at the rounding noise of solving Q(x) = q through erfc).  Taking
+// log q keeps the full precision of tail probabilities far below the double range of q.
+static double norm_isf_log(double lq)
 {
-    if (q == 0.5)
-        return 0.0;
-    const bool flip = q > 0.5;
-    const double qq = flip ? 1.0 - q : q;
-    const double lq = std::log(qq);
-    double t = std::sqrt(-2.0 * lq);
-    double x = t - (2.515517 + t * (0.802853 + t * 0.010328)) /
-                       (1.0 + t * (1.432788 + t * (0.189269 + t * 0.001308)));
-    for (int it = 0; it < 60; it++) {
-        const double Q = norm_sf(x);
-        const double pdf = std::exp(-0.5 * x * x) / std::sqrt(2.0 * M_PI);
-        const double dx = (std::log(Q) - lq) * Q / pdf;
-        x += dx;
-        if (std::fabs(dx) <= 4e-16 * std::max(1.0, std::fabs(x)))
-            break;
+    auto horner8 = [](const double (&c)[8], double r) {
+        double v = c[7];
+        for (int k = 6; k >= 0; k--)
+            v = v * r + c[k];
+        return v;
+    };
+    static const double A[8] = {3.3871328727963666080, 1.3314166789178437745e2, 1.9715909503065514427e3,
+                                1.3731693765509461125e4, 4.5921953931549871457e4, 6.7265770927008700853e4,
+                                3.3430575583588128105e4, 2.5090809287301226727e3};
+    static const double B[8] = {1.0, 4.2313330701600911252e1, 6.8718700749205790830e2, 5.3941960214247511077e3,
+                                2.1213794301586595867e4, 3.9307895800092710610e4, 2.8729085735721942674e4,
+                                5.2264952788528545610e3};
+    static const double Cc[8] = {1.42343711074968357734, 4.63033784615654529590, 5.76949722146069140550,
+                                 3.64784832476320460504, 1.27045825245236838258, 2.41780725177450611770e-1,
+                                 2.27238449892691845833e-2, 7.74545014278341407640e-4};
+    static const double Dd[8] = {1.0, 2.05319162663775882187, 1.67638483018380384940, 6.89767334985100004550e-1,
+                                 1.48103976427480074590e-1, 1.51986665636164571966e-2, 5.47593808499534494600e-4,
+                                 1.05075007164441684324e-9};
+    static const double Ee[8] = {6.65790464350110377720, 5.46378491116411436990, 1.78482653991729133580,
+                                 2.96560571828504891230e-1, 2.65321895265761230930e-2, 1.24266094738807843860e-3,
+                                 2.71155556874348757815e-5, 2.01033439929228813265e-7};
+    static const double Ff[8] = {1.0, 5.99832206555887937690e-1, 1.36929880922735805310e-1, 1.48753612908506148525e-2,
+                                 7.86869131145613259100e-4, 1.84631831751005468180e-5, 1.42151175831644588870e-7,
+                                 2.04426310338993978564e-15};
+    if (lq > -2.5902671654458267) { // q > 0.075: the central form works on q itself
+        const double d = 0.5 - std::exp(lq), r = 0.180625 - d * d;
+        return d * horner8(A, r) / horner8(B, r);
     }
-    return flip ? -x : x;
+    double r = std::sqrt(-lq);
+    if (r <= 5.0) {
+        r -= 1.6;
+        return horner8(Cc, r) / horner8(Dd, r);
+    }
+    r -= 5.0;
+    return horner8(Ee, r) / horner8(Ff, r);
 }
 
 static double equivalent_gaussian_sigma(double logp)
@@ -133,24 +164,28 @@ static double equivalent_gaussian_sigma(double logp)
         const double t = std::sqrt(-2.0 * logp);
         x = t - (2.515517 + t * (0.802853 + t * 0.010328)) /
                     (1.0 + t * (1.432788 + t * (0.189269 + t * 0.001308)));
+    } else if (logp >= 0.0) {
+        x = 0.0;  // p = 1 - q <= 0: the reference maps this DCDFLIB range error to 0 (:474-475)
+                  // (its other range error, q <= 0 -> 38.5 (:476-477), cannot occur above -600)
+    } else if (logp > -0.69314718055994530942) {
+        x = -norm_isf_log(std::log1p(-std::exp(logp))); // q > 1/2: by symmetry from 1 - q; clamped to 0 below
     } else {
-        const double q = std::exp(logp), p = 1.0 - q;
-        if (p <= 0.0 || p > 1.0)
-            x = 0.0;  // the reference maps this DCDFLIB range error to 0 (:474-475)
-        else if (q <= 0.0 || q > 1.0)
-            x = 38.5; // and this one to 38.5 (:476-477)
-        else
-            x = norm_isf(q);
+        x = norm_isf_log(logp);
     }
     return x < 0.0 ? 0.0 : x;
 }
 
-double candidate_sigma(double power, int numsum, double numtrials)
+static double candidate_sigma_logtrials(double power, int numsum, double log_numtrials)
 {
     if (power <= 0.0)
         return 0.0;
-    const double logp = chi2_logp(2.0 * power, 2 * numsum) + std::log(numtrials);
+    const double logp = chi2_logp(2.0 * power, 2 * numsum) + log_numtrials;
     return equivalent_gaussian_sigma(logp);
+}
+
+double candidate_sigma(double power, int numsum, double numtrials)
+{
+    return candidate_sigma_logtrials(power, numsum, std::log(numtrials));
 }
 
 double power_for_sigma(double sigma, int numsum, double numtrials)
@@ -274,15 +309,19 @@ int replay(const accelgpu_setup *s, const accelgpu_hit *hits, int64_t n_hits,
     // calls): computed for all hits up front, on several threads when there are
     // thousands.  The list walk below stays sequential, in the reference's order.
     std::vector<float> sigs((size_t) n_hits);
+    double log_trials[ACCELGPU_MAXSTAGES];
+    for (int st = 0; st < s->numharmstages; st++)
+        log_trials[st] = std::log((double) s->numindep[st]);
     auto sigma_range = [&](int64_t a, int64_t b) {
         for (int64_t i = a; i < b; i++)
-            sigs[(size_t) i] = (float) candidate_sigma(hits[i].power, 1 << hits[i].stage,
-                                                      (double) s->numindep[hits[i].stage]);
+            sigs[(size_t) i] = (float) candidate_sigma_logtrials(hits[i].power, 1 << hits[i].stage,
+                                                                log_trials[hits[i].stage]);
     };
     int nthreads = (int) std::min<int64_t>(n_hits / 2048, 8);
     if (env_threads >= 0)
         nthreads = env_threads;
-    nthreads = std::min<int>(nthreads, (int) std::max(1u, std::thread::hardware_concurrency()));
+    static const int host_cores = (int) std::max(1u, std::thread::hardware_concurrency()); // asked once: it reads sysfs
+    nthreads = std::min<int>(nthreads, host_cores);
     if (nthreads <= 1) {
         sigma_range(0, n_hits);
     } else {

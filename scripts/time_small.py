@@ -38,10 +38,14 @@ def steps(k):
     return nh / k
 steps(20)
 g.synchronize()
-t0 = time.perf_counter()
+# several rounds: the first second or so after start-up runs the host code several times slower
+# (seen on every box: the C replay of one trial's hits takes 160 us at first and 40 us later)
 k = 400
-nh = steps(k)
-g.synchronize()
-el = time.perf_counter() - t0
-print("2^%d points, zmax %d, numharm %d: %.0f searches/s (%.3f ms per search), %.0f hits per trial" % (
-    log2n, zmax, numharm, k / el, 1e3 * el / k, nh))
+rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 6
+for rnd in range(rounds):
+    t0 = time.perf_counter()
+    nh = steps(k)
+    g.synchronize()
+    el = time.perf_counter() - t0
+    print("2^%d points, zmax %d, numharm %d, round %d: %.0f searches/s (%.3f ms per search), %.0f hits per trial" % (
+        log2n, zmax, numharm, rnd, k / el, 1e3 * el / k, nh), flush=True)
