@@ -144,8 +144,18 @@ template <int N, int DIR, int SER = 0> struct Dft {
                 combine<K + 1>(v, e, o);
             return;
         } else {
+            // e + w*o as two fused multiply-adds on top of e, then e - w*o = 2e - (e + w*o) as
+            // a third: three packed instructions per butterfly instead of four (product in
+            // two, sum, difference)
             constexpr int J = K * (32 / N);
-            t = cmul_s(o[K], c32{kCos32[J], DIR * kSin32[J]});
+            const c32 w = c32{kCos32[J], DIR * kSin32[J]}, wq = c32{-DIR * kSin32[J], kCos32[J]};
+            const c32 u = __builtin_elementwise_fma(o[K].xx, w, e[K]);
+            const c32 a = __builtin_elementwise_fma(o[K].yy, wq, u);
+            v[K] = a;
+            v[K + N / 2] = __builtin_elementwise_fma(e[K], c32{2.f, 2.f}, -a);
+            if constexpr (K + 1 < N / 2)
+                combine<K + 1>(v, e, o);
+            return;
         }
         v[K] = e[K] + t;
         v[K + N / 2] = e[K] - t;
