@@ -103,7 +103,6 @@ struct Tuning {
     int std_table = 0;      // standard mode: table-form correlate also at the fundamental's length
     int std_blocks = 0;     // standard mode: search blocks per pass; 0: as many as the scratch holds
     int opt_nt = 512;       // candidate optimisation: threads per workgroup
-    int use_graph = 1;      // launch small searches as one captured graph
 };
 
 struct accelgpu_ctx {
@@ -197,7 +196,6 @@ struct accelgpu_ctx {
     int head = 0, tail = 0, inflight = 0;            // FIFO of launched, uncollected trials
     uint64_t launch_serial = 0;                      // launches so far
     uint64_t plane_serial = 0;                       // the launch whose fundamental the plane holds
-    bool graph_stale = true;                         // a captured launch graph no longer matches the set-up
     hipStream_t copy_stream = nullptr;               // late D2H copies that must not queue behind kernels
     DevHit *d_hits = nullptr;
     DevHit *h_hits = nullptr;
@@ -888,7 +886,7 @@ const TuneName kTuneNames[] = {
     {"hs_lds", &Tuning::hs_lds},             {"hs_lean_from", &Tuning::hs_lean_from},
     {"hs_j", &Tuning::hs_j},                 {"hs_chunk_blocks", &Tuning::hs_chunk_blocks},
     {"std_table", &Tuning::std_table},       {"std_blocks", &Tuning::std_blocks},
-    {"opt_nt", &Tuning::opt_nt},             {"use_graph", &Tuning::use_graph},
+    {"opt_nt", &Tuning::opt_nt},
 };
 
 void tuning_from_env(Tuning *t)
@@ -1102,7 +1100,6 @@ int accelgpu_set_tuning(accelgpu_ctx *ctx, const char *name, int value)
     for (const TuneName &k : kTuneNames)
         if (!strcmp(name, k.name)) {
             ctx->tune.*(k.field) = value;
-            ctx->graph_stale = true;
             return ACCELGPU_OK;
         }
     set_error("accelgpu_set_tuning: no knob named '%s'", name);
