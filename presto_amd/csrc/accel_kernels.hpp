@@ -450,12 +450,12 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate(
 //                      then three rows exp(+2*pi*i*b*lo/N), lo = 1..3
 //   pw2: [R2/4+2][R3]  the same for exp(+2*pi*i*d*e/M1)
 // ---------------------------------------------------------------------------
-template <class P, bool KEEPK, int SER, bool ZL = false>
+template <class P, bool KEEPK, int SER, bool ZL = false, class Stamp = afft::NoStamp>
 __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
     const c32 *__restrict__ bank, const c32 *__restrict__ blockfft,
     const int64_t *__restrict__ blk_col, const int *__restrict__ blk_ncols, int nblk, int chunk,
     float *__restrict__ plane, int64_t rlen, int halfwidth, const c32 *__restrict__ pw1,
-    const c32 *__restrict__ pw2, int numz, int tile_z, int tile_c)
+    const c32 *__restrict__ pw2, int numz, int tile_z, int tile_c, Stamp stamp = Stamp())
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     c32 *lds = reinterpret_cast<c32 *>(smem);
@@ -533,6 +533,8 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
     }
 
     for (int it = b0; it < b1; it++) {
+        stamp.begin(it - b0);
+        stamp(0);
         const int blk = ZL ? ia : it;
         float *out = (ZL ? plane + (size_t) it * (size_t) rlen : prow) + blk_col[blk];
         const int ncols = blk_ncols[blk];
@@ -578,8 +580,9 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
                         dreg[a] = D[P::M1 * a + t];
                 }
             },
-            [&](int n, c32 v) { put(rsrc, n - t, v.x * v.x + v.y * v.y); });
+            [&](int n, c32 v) { put(rsrc, n - t, v.x * v.x + v.y * v.y); }, stamp);
         __syncthreads();
+        stamp(9);
     }
 }
 

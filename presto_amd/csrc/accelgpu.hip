@@ -95,6 +95,7 @@ struct Tuning {
     int corr_chunk = 0;     // transforms per workgroup; 0: 16, fewer on small grids
     int corr_tz = -1;       // XCD tile: owned items per tile; -1: 4 on large grids, plain grid otherwise; 0: plain grid
     int corr_tc = 16;       // XCD tile: chunks per tile
+    int corr_lds = 0;       // plane generation: extra bytes of dynamic LDS (caps the workgroups per CU; experiments)
     int hs_xcd_remap = 1;   // harmonic sum: each XCD takes one contiguous run of columns
     int hs_lds = 0;         // harmonic sum: bytes of dynamic LDS (caps the waves per CU)
     int hs_lean_from = 6;   // harmonic sum: register-lean form from this many stages on
@@ -530,7 +531,7 @@ int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const i
     }
 #define LAUNCH_RR(PLAN, ZL)                                                                    \
     hipLaunchKernelGGL((accelk::k_correlate_rr<PLAN, false, 16, ZL>), rgrid, dim3(PLAN::NT),   \
-                       PLAN::LDS_BYTES, ctx->stream, ctx->d_bank, d_blockfft, d_col, d_ncols,   \
+                       PLAN::LDS_BYTES + std::min(std::max(tn.corr_lds, 0), 20000), ctx->stream, ctx->d_bank, d_blockfft, d_col, d_ncols,   \
                        nblk, chunk, d_plane, rlen, ctx->halfwidth, ctx->pw_inv.pw1,            \
                        ctx->pw_inv.pw2, ctx->numz, tile_z, tile_c)
     if (rr && ctx->fftlen == 8192) {
@@ -882,7 +883,8 @@ struct TuneName {
 const TuneName kTuneNames[] = {
     {"corr_rr", &Tuning::corr_rr},           {"corr_zl", &Tuning::corr_zl},
     {"corr_chunk", &Tuning::corr_chunk},     {"corr_tz", &Tuning::corr_tz},
-    {"corr_tc", &Tuning::corr_tc},           {"hs_xcd_remap", &Tuning::hs_xcd_remap},
+    {"corr_tc", &Tuning::corr_tc},           {"corr_lds", &Tuning::corr_lds},
+            {"hs_xcd_remap", &Tuning::hs_xcd_remap},
     {"hs_lds", &Tuning::hs_lds},             {"hs_lean_from", &Tuning::hs_lean_from},
     {"hs_j", &Tuning::hs_j},                 {"hs_chunk_blocks", &Tuning::hs_chunk_blocks},
     {"std_table", &Tuning::std_table},       {"std_blocks", &Tuning::std_blocks},
@@ -1008,10 +1010,10 @@ int accelgpu_create(accelgpu_ctx **out, int device)
     if ((rc = allow_lds(accelk::k_block_prep<P8K>, P8K::LDS_BYTES + 64))) return rc;
     if ((rc = allow_lds(accelk::k_correlate<P8K, false>, P8K::LDS_BYTES))) return rc;
     if ((rc = allow_lds(accelk::k_correlate<P16K, false>, P16K::LDS_BYTES))) return rc;
-    if ((rc = allow_lds(accelk::k_correlate_rr<P8K, false, 16, false>, P8K::LDS_BYTES))) return rc;
-    if ((rc = allow_lds(accelk::k_correlate_rr<P8K, false, 16, true>, P8K::LDS_BYTES))) return rc;
-    if ((rc = allow_lds(accelk::k_correlate_rr<P16K, false, 16, false>, P16K::LDS_BYTES))) return rc;
-    if ((rc = allow_lds(accelk::k_correlate_rr<P16K, false, 16, true>, P16K::LDS_BYTES))) return rc;
+    if ((rc = allow_lds(accelk::k_correlate_rr<P8K, false, 16, false>, P8K::LDS_BYTES + 20000))) return rc;
+    if ((rc = allow_lds(accelk::k_correlate_rr<P8K, false, 16, true>, P8K::LDS_BYTES + 20000))) return rc;
+    if ((rc = allow_lds(accelk::k_correlate_rr<P16K, false, 16, false>, P16K::LDS_BYTES + 20000))) return rc;
+    if ((rc = allow_lds(accelk::k_correlate_rr<P16K, false, 16, true>, P16K::LDS_BYTES + 20000))) return rc;
     if ((rc = allow_lds(accelk::k_fft_rows<P8K, -1>, P8K::LDS_BYTES))) return rc;
     if ((rc = allow_lds(accelk::k_fft_rows<P16K, -1>, P16K::LDS_BYTES))) return rc;
     if ((rc = allow_lds(speck::k_bigfft_cols<P8K>, P8K::LDS_BYTES))) return rc;

@@ -289,8 +289,17 @@ template <int R> __device__ __forceinline__ void apply_twiddles_2level(c32 *v, c
 // to start global loads that should fly during passes 2 and 3);
 // store(n, v) receives output n.  Ends with all LDS reads done but no trailing
 // barrier: callers that loop must __syncthreads() before reuse.
-template <class P, int DIR, int SER = 0, class Load, class Tw1, class Tw2, class Mid, class Store>
-__device__ __forceinline__ void fft3x(c32 *lds, Load load, Tw1 tw1, Tw2 tw2, Mid mid, Store store)
+// Phase marker hook of fft3x(): does nothing in product kernels; a diagnostic build passes
+// an object that records the cycle counter at each phase boundary.
+struct NoStamp {
+    __device__ __forceinline__ void begin(int) {}
+    __device__ __forceinline__ void operator()(int) const {}
+};
+
+template <class P, int DIR, int SER = 0, class Load, class Tw1, class Tw2, class Mid, class Store,
+          class Stamp = NoStamp>
+__device__ __forceinline__ void fft3x(c32 *lds, Load load, Tw1 tw1, Tw2 tw2, Mid mid, Store store,
+                                      Stamp stamp = Stamp())
 {
     const int t = threadIdx.x;
     c32 v[P::E];
@@ -303,12 +312,15 @@ __device__ __forceinline__ void fft3x(c32 *lds, Load load, Tw1 tw1, Tw2 tw2, Mid
             v[u * P::R1 + a] = load(u, a, b);
         Dft<P::R1, DIR, SER>::run(&v[u * P::R1]);
         tw1(u, b, &v[u * P::R1]);
+        stamp(1); // inputs arrived, pass-1 arithmetic done
 #pragma unroll
         for (int n1 = 0; n1 < P::R1; n1++)
             lds[n1 * P::S1 + b] = v[u * P::R1 + n1];
     }
     mid();
+    stamp(2); // first image written (issued)
     __syncthreads();
+    stamp(3);
 
 #pragma unroll
     for (int u = 0; u < P::B2; u++) {
@@ -318,7 +330,9 @@ __device__ __forceinline__ void fft3x(c32 *lds, Load load, Tw1 tw1, Tw2 tw2, Mid
         for (int c = 0; c < P::R2; c++)
             v[u * P::R2 + c] = lds[n1 * P::S1 + P::R3 * c + d];
     }
+    stamp(4); // first image read (issued)
     __syncthreads(); // every read of image 1 is done before image 2 overwrites it
+    stamp(5);
 #pragma unroll
     for (int u = 0; u < P::B2; u++) {
         const int g = t + P::NT * u;
@@ -329,7 +343,9 @@ __device__ __forceinline__ void fft3x(c32 *lds, Load load, Tw1 tw1, Tw2 tw2, Mid
         for (int e = 0; e < P::R2; e++)
             lds[(e * P::R3 + d) * P::S2 + n1] = v[u * P::R2 + e];
     }
+    stamp(6); // pass-2 arithmetic done, second image written (issued)
     __syncthreads();
+    stamp(7);
 
 #pragma unroll
     for (int u = 0; u < P::B3; u++) {
@@ -343,6 +359,7 @@ __device__ __forceinline__ void fft3x(c32 *lds, Load load, Tw1 tw1, Tw2 tw2, Mid
         for (int f = 0; f < P::R3; f++)
             store(g + P::R1 * P::R2 * f, v[u * P::R3 + f]);
     }
+    stamp(8); // pass-3 arithmetic done, outputs stored (issued)
 }
 
 // Table form: tw1 is the [R1][M1] table of exp(DIR*2*pi*i*b*n1/N), tw2 the
