@@ -103,6 +103,9 @@ int accelgpu_synchronize(accelgpu_ctx *ctx);
  *   std_table      0   standard mode: table-form correlate at the fundamental's length too
  *   std_blocks     0   standard mode: search blocks per pass (0: what the scratch holds)
  *   opt_nt       512   candidate optimisation: threads per workgroup
+ *   use_graph      1   searches with a plane of at most 64 MB: the whole launch is captured once
+ *                      per (hit buffer, spectrum buffer) as a HIP graph and replayed with one call
+ *   corr_lds       0   plane generation: extra bytes of dynamic LDS per workgroup (experiments)
  *   hits_cap   2^20    records in each device hit buffer (set: reallocates both; they
  *                      grow on their own when a search overflows them)
  * ref: none (the reference's only run-time knob is -ncpus). */

@@ -104,6 +104,7 @@ struct Tuning {
     int std_table = 0;      // standard mode: table-form correlate also at the fundamental's length
     int std_blocks = 0;     // standard mode: search blocks per pass; 0: as many as the scratch holds
     int opt_nt = 512;       // candidate optimisation: threads per workgroup
+    int use_graph = 1;      // small searches: one captured graph per launch instead of nine stream operations
 };
 
 struct accelgpu_ctx {
@@ -197,6 +198,19 @@ struct accelgpu_ctx {
     int head = 0, tail = 0, inflight = 0;            // FIFO of launched, uncollected trials
     uint64_t launch_serial = 0;                      // launches so far
     uint64_t plane_serial = 0;                       // the launch whose fundamental the plane holds
+    // Small searches are launch-bound: their whole launch (count reset, block preparation,
+    // plane generation, harmonic sum, copies of the count and of the first hits) is captured
+    // once per (hit slot, spectrum buffer) and replayed with one call.
+    struct LaunchGraph {
+        int slot = 0;
+        const c32 *fft = nullptr;
+        int64_t numbins = 0;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        uint64_t used = 0;
+    };
+    std::vector<LaunchGraph> graphs;
+    uint64_t graph_clock = 0;
     hipStream_t copy_stream = nullptr;               // late D2H copies that must not queue behind kernels
     DevHit *d_hits = nullptr;
     DevHit *h_hits = nullptr;
@@ -262,6 +276,17 @@ int use(accelgpu_ctx *ctx)
     }
     HIPCHK(hipSetDevice(ctx->device));
     return ACCELGPU_OK;
+}
+
+// Captured launches hold kernel arguments (buffers, geometry, knobs): anything that changes
+// one of those drops them all, and the next launch captures afresh.
+void drop_graphs(accelgpu_ctx *ctx)
+{
+    for (auto &g : ctx->graphs) {
+        if (g.exec) (void) hipGraphExecDestroy(g.exec);
+        if (g.graph) (void) hipGraphDestroy(g.graph);
+    }
+    ctx->graphs.clear();
 }
 
 template <class T> int dev_reserve(T **p, size_t *cap, size_t want, bool zero, hipStream_t st)
@@ -661,6 +686,7 @@ void select_slot(accelgpu_ctx *ctx, int i)
 // device, so whatever is queued has finished when this returns.
 int resize_slot(accelgpu_ctx *ctx, int i, size_t want)
 {
+    drop_graphs(ctx);
     accelgpu_ctx::HitSlot &sl = ctx->slots[i];
     if (sl.d_hits) HIPCHK(hipFree(sl.d_hits));
     if (sl.h_hits) HIPCHK(hipHostFree(sl.h_hits));
@@ -781,6 +807,66 @@ int queue_fill_and_sum_chunked(accelgpu_ctx *ctx, int chunk_blocks, const HitTar
     return ACCELGPU_OK;
 }
 
+// Hits copied back speculatively with the count, so that a collect usually finds them all
+// on the host already.
+size_t prefetch_hits(const accelgpu_ctx *ctx, const accelgpu_ctx::HitSlot &sl)
+{
+    const bool small = ctx->setup.plane_bytes <= ((int64_t) 64 << 20);
+    return std::min<size_t>(sl.cap, small ? 8192 : 65536);
+}
+
+// One whole launch of a small search into hit slot `si` as a captured graph, replayed with one
+// call: the nine stream operations of the plain path cost more host time than the GPU work
+// they queue.  The copies are part of the graph (a few microseconds at these sizes).
+int launch_as_graph(accelgpu_ctx *ctx, int si)
+{
+    accelgpu_ctx::HitSlot &sl = ctx->slots[si];
+    accelgpu_ctx::LaunchGraph *g = nullptr;
+    for (auto &e : ctx->graphs)
+        if (e.slot == si && e.fft == ctx->d_fft && e.numbins == ctx->numbins)
+            g = &e;
+    if (!g) {
+        if (ctx->graphs.size() >= 12) { // least recently used one out
+            size_t old = 0;
+            for (size_t k = 1; k < ctx->graphs.size(); k++)
+                if (ctx->graphs[k].used < ctx->graphs[old].used) old = k;
+            if (ctx->graphs[old].exec) (void) hipGraphExecDestroy(ctx->graphs[old].exec);
+            if (ctx->graphs[old].graph) (void) hipGraphDestroy(ctx->graphs[old].graph);
+            ctx->graphs.erase(ctx->graphs.begin() + (std::ptrdiff_t) old);
+        }
+        accelgpu_ctx::LaunchGraph e;
+        e.slot = si;
+        e.fft = ctx->d_fft;
+        e.numbins = ctx->numbins;
+        HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        auto body = [&]() -> int {
+            HIPCHK(hipMemsetAsync(sl.d_count, 0, sizeof(unsigned int), ctx->stream));
+            int rc = queue_fill(ctx);
+            if (rc) return rc;
+            rc = launch_harmsum<false>(ctx, ctx->setup.numharmstages, ctx->col0, (int64_t) ctx->nsearch * ACCELGPU_USELEN,
+                                       nullptr, 0, HitTarget{sl.d_hits, sl.d_count, sl.cap});
+            if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(sl.h_count, sl.d_count, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipMemcpyAsync(sl.h_hits, sl.d_hits, prefetch_hits(ctx, sl) * sizeof(DevHit), hipMemcpyDeviceToHost,
+                                  ctx->stream));
+            return ACCELGPU_OK;
+        };
+        const int rc = body();
+        const hipError_t ee = hipStreamEndCapture(ctx->stream, &e.graph); // always: the stream must leave capture mode
+        if (rc) {
+            if (e.graph) (void) hipGraphDestroy(e.graph);
+            return rc;
+        }
+        HIPCHK(ee);
+        HIPCHK(hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
+        ctx->graphs.push_back(e);
+        g = &ctx->graphs.back();
+    }
+    g->used = ++ctx->graph_clock;
+    HIPCHK(hipGraphLaunch(g->exec, ctx->stream));
+    return ACCELGPU_OK;
+}
+
 int queue_search(accelgpu_ctx *ctx)
 {
     HIPCHK(hipMemsetAsync(ctx->d_count, 0, sizeof(unsigned int), ctx->stream));
@@ -888,7 +974,7 @@ const TuneName kTuneNames[] = {
     {"hs_lds", &Tuning::hs_lds},             {"hs_lean_from", &Tuning::hs_lean_from},
     {"hs_j", &Tuning::hs_j},                 {"hs_chunk_blocks", &Tuning::hs_chunk_blocks},
     {"std_table", &Tuning::std_table},       {"std_blocks", &Tuning::std_blocks},
-    {"opt_nt", &Tuning::opt_nt},
+    {"opt_nt", &Tuning::opt_nt},             {"use_graph", &Tuning::use_graph},
 };
 
 void tuning_from_env(Tuning *t)
@@ -1030,6 +1116,7 @@ int accelgpu_create(accelgpu_ctx **out, int device)
 // Teardown releases what it can: a failing release has nobody left to report to.
 void accelgpu_destroy(accelgpu_ctx *ctx)
 {
+    if (ctx) drop_graphs(ctx);
     if (!ctx)
         return;
     (void) hipSetDevice(ctx->device);
@@ -1102,6 +1189,7 @@ int accelgpu_set_tuning(accelgpu_ctx *ctx, const char *name, int value)
     for (const TuneName &k : kTuneNames)
         if (!strcmp(name, k.name)) {
             ctx->tune.*(k.field) = value;
+            drop_graphs(ctx);
             return ACCELGPU_OK;
         }
     set_error("accelgpu_set_tuning: no knob named '%s'", name);
@@ -1131,6 +1219,7 @@ int accelgpu_set_stream(accelgpu_ctx *ctx, void *hip_stream)
 {
     int rc = use(ctx);
     if (rc) return rc;
+    drop_graphs(ctx);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t) hip_stream : ctx->own_stream;
     return ACCELGPU_OK;
@@ -1162,6 +1251,7 @@ int accelgpu_build_kernels(accelgpu_ctx *ctx, int zmax)
     if (zmax == ctx->zmax)
         return ACCELGPU_OK;
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    drop_graphs(ctx);
     const int numz = (zmax / 2) * 2 + 1;
     const int fftlen = accelhost::calc_fftlen(1, 1, zmax);
     if (fftlen != 8192 && fftlen != 16384) {
@@ -1351,6 +1441,7 @@ int set_search_impl(accelgpu_ctx *ctx, const accelgpu_setup *s, int norm_type, f
         return ACCELGPU_ERR_ARG;
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    drop_graphs(ctx);
     const bool same_geometry = ctx->have_search && ctx->inmem && inmem && ctx->setup.rlo == s->rlo &&
                                ctx->setup.highestbin == s->highestbin &&
                                ctx->setup.lobin == s->lobin && ctx->setup.zmax == s->zmax;
@@ -1515,6 +1606,7 @@ int accelgpu_set_block_range(accelgpu_ctx *ctx, int32_t first_block, int32_t num
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     std::vector<char> need((size_t) ctx->nblk, 0);
+    drop_graphs(ctx);
     const int64_t col0 = ctx->col0;
     if (num_blocks > 0) {
         for (int k = 0; k < num_blocks; k++)
@@ -1614,8 +1706,19 @@ int accelgpu_run_launch(accelgpu_ctx *ctx)
     sl.serial = ++ctx->launch_serial;
     if (ctx->range_count > 0) {
         if ((rc = spectrum_ready(ctx, ctx->stream))) return rc;
-        HIPCHK(hipMemsetAsync(ctx->d_count, 0, sizeof(unsigned int), ctx->stream));
         const bool whole_grid = ctx->nblk_active == ctx->nblk && ctx->range_first == 0 && ctx->range_count == ctx->nsearch;
+        const bool small = ctx->setup.plane_bytes <= ((int64_t) 64 << 20);
+        if (ctx->tune.use_graph && small && whole_grid && ctx->tune.hs_chunk_blocks == 0 && !ctx->profiling &&
+            ctx->stream == ctx->own_stream) {
+            if ((rc = launch_as_graph(ctx, si))) return rc;
+            ctx->plane_serial = sl.serial;
+            sl.prefetch = prefetch_hits(ctx, sl);
+            HIPCHK(hipEventRecord(sl.done, ctx->stream));
+            ctx->tail ^= 1;
+            ctx->inflight++;
+            return ACCELGPU_OK;
+        }
+        HIPCHK(hipMemsetAsync(ctx->d_count, 0, sizeof(unsigned int), ctx->stream));
         if (ctx->tune.hs_chunk_blocks > 0 && whole_grid) {
             if ((rc = queue_fill_and_sum_chunked(ctx, ctx->tune.hs_chunk_blocks, slot_target(ctx)))) return rc;
             ctx->plane_serial = sl.serial;
@@ -1635,7 +1738,7 @@ int accelgpu_run_launch(accelgpu_ctx *ctx)
         HIPCHK(hipMemcpyAsync(sl.h_count, sl.d_count, sizeof(unsigned int), hipMemcpyDeviceToHost,
                               ctx->copy_stream));
         // speculative copy of the head of the hit buffer: usually all of them
-        const size_t pre = std::min<size_t>(sl.cap, 65536);
+        const size_t pre = prefetch_hits(ctx, sl);
         HIPCHK(hipMemcpyAsync(sl.h_hits, sl.d_hits, pre * sizeof(DevHit), hipMemcpyDeviceToHost,
                               ctx->copy_stream));
         sl.prefetch = pre;

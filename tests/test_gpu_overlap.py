@@ -15,6 +15,11 @@ N, DT, ZMAX, NH = 1 << 20, 1e-4, 20, 8
 
 @pytest.fixture(scope="module")
 def gpu():
+    # torch (the allocator of the caller-owned device buffers below) first: its wheel brings
+    # its own copy of the HIP runtime, and initialising that one after this library's has
+    # been working for a while was seen to fail ("No HIP GPUs are available")
+    import torch
+    torch.cuda.init()
     g = pa.AccelSearchGPU(0)
     yield g
     g.close()
@@ -169,3 +174,63 @@ def test_device_hit_buffer_overflow_with_a_later_trial_queued(gpu):
             gpu.run_collect()
     finally:
         gpu.set_tuning("hits_cap", 1 << 20)
+
+
+def test_graph_launch_equals_plain_launch(gpu):
+    """Small searches (plane <= 64 MB) are launched as one captured graph per (hit slot,
+    spectrum buffer): same hits as the plain stream path, pipelined two deep, from library
+    buffers, caller's device buffers and page-locked uploads, through a hit-buffer overflow
+    (which drops the captured graphs) and across a change of geometry."""
+    import torch
+    from presto_amd.api import PinnedSpectrum
+    g = pa.AccelSearchGPU(0)
+    try:
+        specs = _spectra()
+        for zmax, nh in ((6, 8), (0, 4)):
+            setup = g.configure(N // 2, N, DT, zmax, nh, fhi=4000.0)
+            assert setup.plane_bytes <= 64 << 20
+            g.set_tuning("use_graph", 0)
+            want = []
+            for s in specs:
+                g.load_fft(s)
+                want.append(g.run())
+            assert min(len(w) for w in want) > 100
+            g.set_tuning("use_graph", 1)
+
+            def pipelined(load):
+                got = []
+                load(0)
+                g.run_launch()
+                load(1)
+                g.run_launch()
+                for k in range(2 * len(specs)):
+                    got.append(g.run_collect())
+                    if k + 2 < 2 * len(specs):
+                        load(k + 2)
+                        g.run_launch()
+                return got
+
+            dev = [torch.from_numpy(s.view(np.float32).copy()).to("cuda:0") for s in specs]
+            pinned = []
+            for s in specs:
+                p = PinnedSpectrum(s.size)
+                p.array[:] = s
+                pinned.append(p)
+            loaders = {
+                "library buffers": lambda k: g.load_fft(specs[k % len(specs)]),
+                "caller's device buffers": lambda k: g.load_fft_device(dev[k % len(specs)].data_ptr(), N // 2,
+                                                                       keepalive=dev[k % len(specs)]),
+                "page-locked uploads": lambda k: g.load_fft_async(pinned[k % len(specs)]),
+            }
+            for name, load in loaders.items():
+                for k, hits in enumerate(pipelined(load)):
+                    assert np.array_equal(hits, want[k % len(specs)]), (zmax, name, k)
+            # overflow of the device hit buffer: re-run inside the collect, graphs dropped and rebuilt
+            g.set_tuning("hits_cap", 64)
+            for k, hits in enumerate(pipelined(loaders["library buffers"])):
+                assert np.array_equal(hits, want[k % len(specs)]), (zmax, "small hit buffer", k)
+            g.set_tuning("hits_cap", 1 << 20)
+            for p in pinned:
+                p.free()
+    finally:
+        g.close()
