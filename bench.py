@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--trials", type=int, default=4, help="distinct spectra resident per GPU")
     ap.add_argument("--log2n", type=int, default=23)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N > 1 code path (RCCL process group, candidate all-gather, max over ranks) "
+                         "whatever the world size: a one-GPU rehearsal of the multi-GPU launch")
     ap.add_argument("--timed-only", action="store_true",
                     help="skip the legs reported beside the metric (PCIe-inclusive, with optimisation, CPU baseline): "
                          "what a profiler then sees is the timed region alone")
@@ -70,7 +73,10 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
+        if "MASTER_ADDR" not in os.environ:            # plain `python bench.py --force-dist`
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     cfg = dict(synth.CONFIGS["cfg2"])
@@ -116,23 +122,28 @@ def main():
     def barrier():
         g.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def merge(results):
+        # the per-trial candidate lists of all ranks, merged (RCCL all-gather over xGMI)
+        recs = [batch.cands_to_records(rank * len(results) + i, c) for i, (_, c) in enumerate(results)]
+        return batch.merge_sorted(batch.allgather_records(np.concatenate(recs), dev))
+
     if args.warmup > 0:
-        run_steps(args.warmup)
+        warm = run_steps(args.warmup)
+        if multi:
+            merge(warm)             # the collectives' first-use set-up belongs to the warm-up too
     g.timings(reset=True)
     barrier()
     t0 = time.perf_counter()
     results = run_steps(args.steps)
-    if world > 1:
-        # merge the per-trial candidate lists of all ranks (RCCL all-gather over xGMI)
-        recs = [batch.cands_to_records(rank * args.steps + i, c) for i, (_, c) in enumerate(results)]
-        merged = batch.merge_sorted(batch.allgather_records(np.concatenate(recs), dev))
+    if multi:
+        merged = merge(results)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
@@ -279,7 +290,7 @@ def main():
                           % (int(np.log2(Ns)), nb_s, nb_full, dt_s)}
         print(json.dumps(line))
     g.close()
-    if world > 1:
+    if multi:
         dist.barrier()          # rank 0 reports a little longer; leave together
         dist.destroy_process_group()
 
