@@ -14,6 +14,11 @@
  *   median()  src/median.c:12-69        <-> orc_median()
  *   cdfchi()/cdfnor() src/dcdflib.c     <-> orc_power_for_sigma()/orc_candidate_sigma()
  *   amoeba()  src/amoeba.c:18-75        <-> orc_amoeba() (the simplex of the candidate optimisation)
+ * and the reference's generated command-line parsers, also unmodified
+ * (oracle/_ref/libaccelsearch_cmd.so, librednoise_cmd.so), which pin the product's flag
+ * names, defaults and limits:
+ *   parseCmdline() src/accelsearch_cmd.c:1028-1203 <-> accelsearch_hip's command line
+ *   parseCmdline() src/rednoise_cmd.c              <-> the rednoise defaults 6 / 100 / 6.0
  * The z-response is additionally pinned against direct quadrature of its
  * defining integral, and the FFT against a double-precision DFT.
  *

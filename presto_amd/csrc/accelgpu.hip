@@ -1230,6 +1230,8 @@ int accelgpu_synchronize(accelgpu_ctx *ctx)
     int rc = use(ctx);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (hipStream_t st : {ctx->copy_stream, ctx->side_stream, ctx->opt_stream})
+        if (st) HIPCHK(hipStreamSynchronize(st));
     for (int j = 0; j < accelgpu_ctx::kOwn; j++)
         if (ctx->own_pending[j]) {
             HIPCHK(hipEventSynchronize(ctx->own_ready[j]));

@@ -65,6 +65,10 @@ int main(int argc, char **argv)
     double sigma = 2.0, flo = 1.0, fhi = 10000.0, baryv = 0.0;
     std::string zaplist;
     bool photon = false, force_inmem = false, force_standard = false, polish = true, harmremove = true;
+    bool showopts = false, median = false, otheropt = false;
+    int ncpus = 1;
+    double rlo = 0.0, rhi = 0.0;
+    int nfiles = 0;
     std::string infile;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -83,22 +87,37 @@ int main(int argc, char **argv)
         else if (a == "-lobin") lobin = atoll(need("-lobin"));
         // -rlo/-rhi never take effect in the reference either: its parser marks -flo and
         // -fhi as always present, and they win (src/accel_utils.c:1581-1624)
-        else if (a == "-rlo" || a == "-rhi" || a == "-ncpus") (void) need(a.c_str());
+        else if (a == "-rlo") rlo = atof(need("-rlo"));
+        else if (a == "-rhi") rhi = atof(need("-rhi"));
+        else if (a == "-ncpus") ncpus = atoi(need("-ncpus"));
+        else if (a == "-showopts") showopts = true; // prints what was understood and stops (tests)
         else if (a == "-zaplist") zaplist = need("-zaplist");
         else if (a == "-baryv") baryv = atof(need("-baryv"));
         else if (a == "-device") device = atoi(need("-device"));
         else if (a == "-photon") photon = true;
         else if (a == "-locpow") norm_type = 1;
-        else if (a == "-median") norm_type = 0;
+        else if (a == "-median") median = true;
         else if (a == "-inmem") force_inmem = true;
         else if (a == "-standard") force_standard = true;
         else if (a == "-noharmpolish") polish = false;
         else if (a == "-noharmremove") harmremove = false;
-        else if (a == "-otheropt") {}
+        else if (a == "-otheropt") otheropt = true;
         else if (a[0] == '-') {
             printf("\nUnknown option '%s'\n\n", a.c_str());
             return 1;
-        } else infile = a;
+        } else {
+            infile = a;
+            nfiles++;
+        }
+    }
+    // the limits of the reference's generated parser (src/accelsearch_cmd.c:1040-1180)
+    if (nfiles != 1) {
+        printf("\nthere should be exactly 1 non-option argument (the .fft or .[s]dat file)\n\n");
+        return 1;
+    }
+    if (ncpus < 1 || lobin < 0 || numharm < 1 || numharm > 32 || rlo < 0.0 || rhi < 0.0 || flo < 0.0 || fhi < 0.0) {
+        printf("\n-ncpus must be >= 1, -lobin, -rlo, -rhi, -flo and -fhi >= 0 and -numharm in 1..32\n\n");
+        return 1;
     }
     auto ends_with = [&](const char *suf) {
         const size_t n = strlen(suf);
@@ -118,6 +137,14 @@ int main(int argc, char **argv)
     if (zmax < 0 || zmax > 1200 || sigma < 1.0 || sigma > 30.0) {
         printf("\n-zmax must be in 0..1200 and -sigma in 1..30\n\n");
         return 1;
+    }
+    if (showopts) {
+        printf("ncpus=%d lobin=%lld numharm=%d zmax=%d sigma=%.9g rlo=%.17g rhi=%.17g flo=%.17g fhi=%.17g inmem=%d "
+               "photon=%d median=%d locpow=%d zaplist=%s baryv=%.17g otheropt=%d noharmpolish=%d noharmremove=%d file=%s\n",
+               ncpus, lobin, numharm, zmax, (double) (float) sigma, rlo, rhi, flo, fhi, (int) force_inmem, (int) photon,
+               (int) median, norm_type, zaplist.empty() ? "-" : zaplist.c_str(), baryv, (int) otheropt, (int) !polish,
+               (int) !harmremove, infile.c_str());
+        return 0;
     }
     const std::string root = infile.substr(0, infile.size() - (is_sdat ? 5 : 4));
     double Nd = 0, dt = 0;

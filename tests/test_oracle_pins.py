@@ -3,7 +3,8 @@
 Pinned against the reference's own code (the five self-contained files built
 unmodified into oracle/_ref/libprestoref.so): Fresnel integrals, the quickselect
 median, the chi^2 / normal routines behind power_for_sigma and candidate_sigma,
-and the downhill simplex of the candidate optimisation.  Pinned against mathematics: the z-response versus quadrature
+the downhill simplex of the candidate optimisation, and (two more unmodified files, the
+generated parsers accelsearch_cmd.c and rednoise_cmd.c) the command line.  Pinned against mathematics: the z-response versus quadrature
 of its defining integral, the FFT versus a double-precision DFT.  Checked against an
 independent evaluation of the reference's set-up formulas (tests/golden/setup_tables.json,
 computed with SciPy, not output of the reference program): half-widths, FFT lengths,
@@ -273,3 +274,126 @@ def test_deredden_whitens_and_is_deterministic(oracle):
     nrm = np.float32(y * np.float32(np.float32(1.5) - np.float32(np.float32(np.float32(np.float32(0.5) * x) * y) * y)))
     assert out[1].real == np.float32(spec[1].real * nrm) and out[3].imag == np.float32(spec[3].imag * nrm)
     assert np.array_equal(out, oracle.deredden(spec))
+
+
+# ---------------------------------------------------------------------------
+# Command-line surface: the product's accelsearch_hip against the reference's own generated
+# parser (src/accelsearch_cmd.c, compiled unmodified into oracle/_ref/libaccelsearch_cmd.so).
+# The reference parser exit()s on errors, so it runs in a child process.
+# ---------------------------------------------------------------------------
+_REF_CLI = r'''
+import ctypes as C, json, sys
+class Cmdline(C.Structure):           # include/accelsearch_cmd.h:11-75
+    _fields_ = [("ncpusP", C.c_char), ("ncpus", C.c_int), ("ncpusC", C.c_int),
+                ("lobinP", C.c_char), ("lobin", C.c_int), ("lobinC", C.c_int),
+                ("numharmP", C.c_char), ("numharm", C.c_int), ("numharmC", C.c_int),
+                ("zmaxP", C.c_char), ("zmax", C.c_int), ("zmaxC", C.c_int),
+                ("sigmaP", C.c_char), ("sigma", C.c_float), ("sigmaC", C.c_int),
+                ("rloP", C.c_char), ("rlo", C.c_double), ("rloC", C.c_int),
+                ("rhiP", C.c_char), ("rhi", C.c_double), ("rhiC", C.c_int),
+                ("floP", C.c_char), ("flo", C.c_double), ("floC", C.c_int),
+                ("fhiP", C.c_char), ("fhi", C.c_double), ("fhiC", C.c_int),
+                ("inmemP", C.c_char), ("photonP", C.c_char), ("medianP", C.c_char), ("locpowP", C.c_char),
+                ("zaplistP", C.c_char), ("zaplist", C.c_char_p), ("zaplistC", C.c_int),
+                ("baryvP", C.c_char), ("baryv", C.c_double), ("baryvC", C.c_int),
+                ("otheroptP", C.c_char), ("noharmpolishP", C.c_char), ("noharmremoveP", C.c_char),
+                ("argc", C.c_int), ("argv", C.POINTER(C.c_char_p)), ("full_cmd_line", C.c_char_p)]
+lib = C.CDLL(sys.argv[1])
+lib.parseCmdline.restype = C.POINTER(Cmdline)
+args = [b"accelsearch"] + [a.encode() for a in sys.argv[2:]]
+argv = (C.c_char_p * (len(args) + 1))(*args, None)
+c = lib.parseCmdline(len(args), argv).contents
+b = lambda x: int(x != b"\x00")
+print(json.dumps(dict(ncpus=c.ncpus, lobin=c.lobin, numharm=c.numharm, zmax=c.zmax, sigma=c.sigma, rlo=c.rlo, rhi=c.rhi,
+                      flo=c.flo, fhi=c.fhi, floP=b(c.floP), fhiP=b(c.fhiP), rloP=b(c.rloP), rhiP=b(c.rhiP),
+                      inmem=b(c.inmemP), photon=b(c.photonP), median=b(c.medianP), locpow=b(c.locpowP),
+                      zaplist=c.zaplist.decode() if c.zaplist else "-", baryv=c.baryv, otheropt=b(c.otheroptP),
+                      noharmpolish=b(c.noharmpolishP), noharmremove=b(c.noharmremoveP),
+                      file=c.argv[0].decode() if c.argc == 1 else None)))
+'''
+
+
+def _ref_cli(args):
+    import subprocess
+    import sys
+    so = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "libaccelsearch_cmd.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libaccelsearch_cmd.so not built (reference tree absent)")
+    r = subprocess.run([sys.executable, "-c", _REF_CLI, so] + args, capture_output=True, timeout=60)
+    return r.returncode, (json.loads(r.stdout.decode().strip().splitlines()[-1]) if r.returncode == 0 else None)
+
+
+def _our_cli(args):
+    import subprocess
+    exe = os.path.join(os.path.dirname(HERE), "presto_amd", "host", "accelsearch_hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "-s"])
+    r = subprocess.run([exe, "-showopts"] + args, capture_output=True, timeout=60)
+    if r.returncode != 0:
+        return r.returncode, None
+    kv = dict(tok.split("=", 1) for tok in r.stdout.decode().split())
+    return 0, kv
+
+
+@pytest.mark.parametrize("args", [
+    ["x.fft"],
+    ["-zmax", "51", "-numharm", "16", "-sigma", "3.5", "-flo", "2", "-fhi", "900.5", "x.fft"],
+    ["-rlo", "5", "-rhi", "70000", "-lobin", "1000", "-inmem", "-ncpus", "4", "y_DM12.30.fft"],
+    ["-photon", "-noharmpolish", "-noharmremove", "-otheropt", "-zmax", "0", "-numharm", "1", "z.dat"],
+    ["-locpow", "-median", "-zaplist", "birds.zaplist", "-baryv", "-0.0001", "-sigma", "30", "-zmax", "1200",
+     "-numharm", "32", "t.sdat"],
+])
+def test_command_line_matches_the_reference_parser(args):
+    rc_r, want = _ref_cli(args)
+    rc_o, got = _our_cli(args)
+    assert rc_r == 0 and rc_o == 0
+    for k in ("ncpus", "lobin", "numharm", "zmax", "inmem", "photon", "median", "locpow", "otheropt", "noharmpolish",
+              "noharmremove"):
+        assert int(got[k]) == int(want[k]), k
+    for k in ("sigma", "rlo", "rhi", "flo", "fhi", "baryv"):
+        assert float(got[k]) == float(want[k]), k
+    assert got["zaplist"] == want["zaplist"] and got["file"] == want["file"]
+    # -flo and -fhi count as given whatever the command line says (defaults 1 Hz and 10 kHz):
+    # the reason -rlo/-rhi never take effect (src/accel_utils.c:1581-1624)
+    assert want["floP"] == 1 and want["fhiP"] == 1
+
+
+@pytest.mark.parametrize("args", [
+    ["-zmax", "1201", "x.fft"], ["-zmax", "-2", "x.fft"], ["-sigma", "0.5", "x.fft"], ["-sigma", "31", "x.fft"],
+    ["-numharm", "64", "x.fft"], ["-numharm", "0", "x.fft"], ["-baryv", "0.2", "x.fft"], ["-lobin", "-1", "x.fft"],
+    ["-flo", "-1", "x.fft"], ["-nosuchflag", "x.fft"], [], ["a.fft", "b.fft"], ["-zmax"],
+])
+def test_command_line_rejects_what_the_reference_parser_rejects(args):
+    rc_r, _ = _ref_cli(args)
+    rc_o, _ = _our_cli(args)
+    assert rc_r != 0 and rc_o != 0
+
+
+def test_rednoise_defaults_match_the_reference_parser():
+    """startwidth 6, endwidth 100, endfreq 6.0: src/rednoise_cmd.c (clig/rednoise_cmd.cli:13-21),
+    compiled unmodified, against the defaults of the host layer's rednoise()."""
+    import inspect
+    import subprocess
+    import sys
+    import presto_amd.api as api
+    so = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "librednoise_cmd.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/librednoise_cmd.so not built (reference tree absent)")
+    code = r'''
+import ctypes as C, sys
+class Cmdline(C.Structure):           # include/rednoise_cmd.h
+    _fields_ = [("startwidthP", C.c_char), ("startwidth", C.c_int), ("startwidthC", C.c_int),
+                ("endwidthP", C.c_char), ("endwidth", C.c_int), ("endwidthC", C.c_int),
+                ("endfreqP", C.c_char), ("endfreq", C.c_double), ("endfreqC", C.c_int),
+                ("argc", C.c_int), ("argv", C.POINTER(C.c_char_p)), ("full_cmd_line", C.c_char_p)]
+lib = C.CDLL(sys.argv[1])
+lib.parseCmdline.restype = C.POINTER(Cmdline)
+args = [b"rednoise", b"x.fft"]
+argv = (C.c_char_p * 3)(*args, None)
+c = lib.parseCmdline(2, argv).contents
+print(c.startwidth, c.endwidth, c.endfreq)
+'''
+    out = subprocess.check_output([sys.executable, "-c", code, so], timeout=60).decode().split()
+    sig = inspect.signature(api.AccelSearchGPU.rednoise).parameters
+    assert (int(out[0]), int(out[1]), float(out[2])) == (sig["startwidth"].default, sig["endwidth"].default,
+                                                         sig["endfreq"].default) == (6, 100, 6.0)
