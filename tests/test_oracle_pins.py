@@ -397,3 +397,21 @@ print(c.startwidth, c.endwidth, c.endfreq)
     sig = inspect.signature(api.AccelSearchGPU.rednoise).parameters
     assert (int(out[0]), int(out[1]), float(out[2])) == (sig["startwidth"].default, sig["endwidth"].default,
                                                          sig["endfreq"].default) == (6, 100, 6.0)
+
+
+@pytest.mark.parametrize("args", [
+    [], ["-zmax", "300", "-numharm", "16", "-sigma", "4", "-flo", "0.5", "-fhi", "2000"],
+    ["-locpow", "-noharmpolish", "-noharmremove", "-baryv", "0.00003", "-zaplist", "b.zaplist"],
+])
+def test_batch_driver_search_flags_match_the_reference_parser(args):
+    """presto_amd.pipeline takes accelsearch's search flags under their own names, with the
+    reference parser's defaults."""
+    from presto_amd import pipeline
+    rc, want = _ref_cli(args + ["x.fft"])
+    assert rc == 0
+    got = pipeline.parse_args(args + ["x.fft"])
+    assert (got.zmax, got.numharm, got.sigma, got.flo, got.fhi, got.baryv) == \
+        (want["zmax"], want["numharm"], want["sigma"], want["flo"], want["fhi"], want["baryv"])
+    assert (int(got.locpow), int(got.noharmpolish), int(got.noharmremove)) == \
+        (want["locpow"], want["noharmpolish"], want["noharmremove"])
+    assert (got.zaplist or "-") == want["zaplist"]
