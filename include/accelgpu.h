@@ -271,6 +271,13 @@ int accelgpu_replay_candidates(const accelgpu_setup *setup, const accelgpu_hit *
                                int64_t n_hits, accelgpu_cand *cands, int64_t max_cands,
                                int64_t *n_cands, float *sigma_out, int32_t *added);
 
+/* How the replay works, never what it returns (process-wide): linear_walk != 0 finds every
+ * hit's place in the list by the reference's walk from the head (src/accel_utils.c:318-330)
+ * instead of a binary search over the list's running maximum -- the check of one against
+ * the other; threads >= 0 fixes the number of host threads that compute sigmas (-1, the
+ * default: by the number of hits, at most 8).  ref: none. */
+int accelgpu_replay_options(int linear_walk, int threads);
+
 /* ---- after the search: candidate list trimming and optimisation -------------- */
 #define ACCELGPU_MAXHARM 32
 /* ref: rderivs, include/presto.h:161-169 */

@@ -106,6 +106,7 @@ def load_library():
     L.accelgpu_run_launch.argtypes = [vp]
     L.accelgpu_run_collect.argtypes = [vp, vp, i64, C.POINTER(i64)]
     L.accelgpu_replay_candidates.argtypes = [pS, vp, i64, vp, i64, C.POINTER(i64), vp, vp]
+    L.accelgpu_replay_options.argtypes = [i, i]
     L.accelgpu_fund_block.argtypes = [vp, d, vp, C.POINTER(C.c_int32)]
     L.accelgpu_summed_block.argtypes = [vp, i, i, vp]
     p32 = C.POINTER(C.c_int32)
@@ -213,6 +214,12 @@ def sort_and_eliminate(cands, eliminate=True):
     n = C.c_int64(0)
     _check(load_library().accelgpu_sort_and_eliminate(_ptr(c), c.size, int(bool(eliminate)), C.byref(n)))
     return c[:n.value].copy()
+
+
+def replay_options(linear_walk=False, threads=-1):
+    """How replay_candidates() works (never what it returns): the reference's plain list
+    walk instead of the binary search; a fixed number of sigma threads."""
+    _check(load_library().accelgpu_replay_options(int(bool(linear_walk)), int(threads)))
 
 
 def replay_candidates(setup, hits):

@@ -1,6 +1,7 @@
 // accel_host.cpp -- host-side logic of libaccelgpu: search planning, detection
 // statistics and the candidate-list replay.  No GPU calls in this file.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -285,6 +286,15 @@ struct Entry {
     double z;
 };
 
+static std::atomic<bool> g_replay_linear{false};
+static std::atomic<int> g_replay_threads{-1};
+
+void replay_options(int linear_walk, int threads)
+{
+    g_replay_linear.store(linear_walk != 0);
+    g_replay_threads.store(threads);
+}
+
 int replay(const accelgpu_setup *s, const accelgpu_hit *hits, int64_t n_hits,
            accelgpu_cand *cands, int64_t max_cands, int64_t *n_cands, float *sigma_out,
            int32_t *added_out)
@@ -294,10 +304,10 @@ int replay(const accelgpu_setup *s, const accelgpu_hit *hits, int64_t n_hits,
     std::vector<double> pmax; // running maximum of list[..].r, same length as list
     list.reserve(1024);
     pmax.reserve(1024);
-    // read once per process: ACCELGPU_REPLAY_LINEAR selects the plain list walk (the check
-    // for the binary search below), ACCELGPU_HOST_THREADS the threads that compute sigmas
-    static const bool linear_walk = std::getenv("ACCELGPU_REPLAY_LINEAR") != nullptr;
-    static const int env_threads = std::getenv("ACCELGPU_HOST_THREADS") ? std::atoi(std::getenv("ACCELGPU_HOST_THREADS")) : -1;
+    // replay_options(): the plain list walk (the check of the binary search below) and the
+    // number of threads that compute sigmas; neither changes a result
+    const bool linear_walk = g_replay_linear.load(std::memory_order_relaxed);
+    const int env_threads = g_replay_threads.load(std::memory_order_relaxed);
     const double zlo = s->zlo;
     for (int64_t i = 0; i < n_hits; i++)
         if (hits[i].stage < 0 || hits[i].stage >= s->numharmstages) {

@@ -21,6 +21,11 @@ int plan(int64_t numbins, int64_t N, double dt, int zmax, int numharm, double si
 int replay(const accelgpu_setup *s, const accelgpu_hit *hits, int64_t n_hits, accelgpu_cand *cands,
            int64_t max_cands, int64_t *n_cands, float *sigma_out, int32_t *added_out);
 
+// How replay() works, not what it returns: linear_walk != 0 finds a hit's place in the list by
+// the reference's walk from the head instead of the binary search; threads >= 0 fixes the number
+// of threads that compute sigmas (-1: by the number of hits).
+void replay_options(int linear_walk, int threads);
+
 // Sort by decreasing sigma, optionally drop harmonically related candidates;
 // returns the number kept (in place, at the front).
 int64_t sort_and_eliminate(accelgpu_cand *cands, int64_t n, bool eliminate);

@@ -1031,6 +1031,12 @@ int accelgpu_replay_candidates(const accelgpu_setup *setup, const accelgpu_hit *
     return accelhost::replay(setup, hits, n_hits, cands, max_cands, n_cands, sigma_out, added);
 }
 
+int accelgpu_replay_options(int linear_walk, int threads)
+{
+    accelhost::replay_options(linear_walk, threads);
+    return ACCELGPU_OK;
+}
+
 int accelgpu_create(accelgpu_ctx **out, int device)
 {
     if (!out) {

@@ -20,5 +20,5 @@ ms = t["total_ms"] / t["launches"]
 S = {1: 0, 2: .25, 4: .875, 8: 2.1875, 16: 4.84375, 32: 10.171875}[nh]
 alg = 4 * (1 + S) * setup.numz * 7470 * setup.num_search_blocks
 print("J=%s remap=%s nh=%d zmax=%d: %.3f ms  alg %.2f GB -> %.0f GB/s (%.1f%% of 8 TB/s) hits %d" % (
-    os.environ.get("ACCELGPU_HARM_J", "0"), "off" if os.environ.get("ACCELGPU_NO_XCD_REMAP") else "on",
+    os.environ.get("ACCELGPU_HS_J", "0"), "off" if os.environ.get("ACCELGPU_HS_XCD_REMAP") == "0" else "on",
     nh, zmax, ms, alg / 1e9, alg / ms / 1e6, alg / ms / 1e6 / 80, len(h)))

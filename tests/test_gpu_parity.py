@@ -221,19 +221,21 @@ def test_tiled_correlate_grid_equals_plain_grid(gpu, monkeypatch):
     setup = gpu.configure(numbins, 2 * numbins, 64e-6, 200, 8, fhi=1e9)
     gpu.load_fft(fft)
     assert setup.numz * ((setup.num_search_blocks + setup.num_prepop_blocks + 15) // 16) >= 4096
-    monkeypatch.delenv("ACCELGPU_CORR_TZ", raising=False)
-    monkeypatch.delenv("ACCELGPU_CORR_TC", raising=False)
+    default_tz, default_tc = gpu.get_tuning("corr_tz"), gpu.get_tuning("corr_tc")
     ref_hits = gpu.run()
     rows = [(0, 0), (100, 2 * 300000 - 64), (setup.numz - 1, setup.rlen - 40000)]
     ref_rows = [gpu.get_plane(z, c, 30000).copy() for z, c in rows]
     assert len(ref_hits) > 0
     for tz, tc in ((0, 1), (1, 1), (3, 5), (7, 64), (64, 3)):
-        monkeypatch.setenv("ACCELGPU_CORR_TZ", str(tz))
-        monkeypatch.setenv("ACCELGPU_CORR_TC", str(tc))
+        gpu.set_tuning("corr_tz", tz)
+        gpu.set_tuning("corr_tc", tc)
+        assert (gpu.get_tuning("corr_tz"), gpu.get_tuning("corr_tc")) == (tz, tc)
         hits = gpu.run()
         assert np.array_equal(hits, ref_hits), (tz, tc)
         for (z, c), want in zip(rows, ref_rows):
             assert np.array_equal(gpu.get_plane(z, c, 30000), want), (tz, tc, z)
+    gpu.set_tuning("corr_tz", default_tz)
+    gpu.set_tuning("corr_tc", default_tc)
 
 
 def test_async_launch_collect_equals_run(gpu):

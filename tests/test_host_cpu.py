@@ -235,12 +235,12 @@ def test_product_writer_reproduces_golden_accel_file(tmp_path):
     assert len(cl) == len(opt) and cl[0].DM == 7.5 and cl[0].numharm == opt["numharm"][0]
 
 
-def test_replay_binary_search_equals_the_plain_walk(monkeypatch):
+def test_replay_binary_search_equals_the_plain_walk():
     """The candidate-list replay finds its place in the list by a binary search over
     running maxima; the reference walks from the head.  Same lists, same per-hit flags,
     on clustered hits that overwrite, erase and insert out of order."""
     import presto_amd as pa
-    from presto_amd.api import replay_candidates, plan
+    from presto_amd.api import replay_candidates, replay_options, plan
     setup = plan(1 << 22, 1 << 23, 64e-6, 200, 16, fhi=1e9)
     rng = np.random.default_rng(5)
     for trial, (n, ncen, spread) in enumerate([(20000, 60, 40), (30000, 700, 12), (5000, 5, 300), (3000, 3000, 1)]):
@@ -252,16 +252,16 @@ def test_replay_binary_search_equals_the_plain_walk(monkeypatch):
         hits["rind"] = (centres[rng.integers(0, ncen, n)] + rng.integers(-spread, spread + 1, n)).astype(np.int64)
         hits["block"] = hits["rind"] // 7470
         hits = hits[np.lexsort((hits["rind"], hits["zind"], hits["stage"], hits["block"]))]
-        monkeypatch.setenv("ACCELGPU_REPLAY_LINEAR", "1")
+        replay_options(linear_walk=True, threads=1)
         c0, s0, a0 = replay_candidates(setup, hits)
-        monkeypatch.delenv("ACCELGPU_REPLAY_LINEAR")
+        replay_options()
         c1, s1, a1 = replay_candidates(setup, hits)
         assert len(c0) > 2 and np.array_equal(c0, c1), trial
         assert np.array_equal(s0, s1) and np.array_equal(a0, a1)
         # and in an order the search never produces (r not even nearly sorted)
         perm = rng.permutation(n)
-        monkeypatch.setenv("ACCELGPU_REPLAY_LINEAR", "1")
+        replay_options(linear_walk=True, threads=1)
         c0, s0, a0 = replay_candidates(setup, hits[perm])
-        monkeypatch.delenv("ACCELGPU_REPLAY_LINEAR")
+        replay_options()
         c1, s1, a1 = replay_candidates(setup, hits[perm])
         assert np.array_equal(c0, c1) and np.array_equal(a0, a1)
