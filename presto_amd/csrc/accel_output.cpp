@@ -79,6 +79,8 @@ void write_header(FILE *f, const std::vector<Column> &cols, const char *bottom3 
 // One significant digit of error.  src/output.c:6-114.
 std::string nice_output_1(double val, double err)
 {
+    if (!std::isfinite(val) || !std::isfinite(err)) // the reference's integer conversions are undefined here
+        return fmt("% g(%g)", val, err);
     int errexp = decade(err);
     int errval = (int) std::floor(std::fabs(err) * p10(-errexp) + kTiny + 0.5);
     if (errval == 10) {
@@ -121,6 +123,8 @@ std::string nice_output_2(double val, double err, bool *ok)
 {
     if (ok)
         *ok = true;
+    if (!std::isfinite(val) || !std::isfinite(err)) // as in nice_output_1
+        return fmt("% g(%g)", val, err);
     int errexp = decade(err);
     int errval = (int) std::floor(std::fabs(err) * p10(-errexp + 1) + kTiny + 0.5);
     if (errval == 100) {
