@@ -347,3 +347,24 @@ def test_locpow_normalisation(gpu, oracle):
     assert len(rel) >= 0.98 * len(want_hits) and rel.max() <= 10 * PLANE_TOL
     assert (edge_g <= 4 * PLANE_TOL).all() and (edge_w <= 4 * PLANE_TOL).all()
     s.close()
+
+
+def test_series_too_short_for_one_block(gpu, oracle):
+    """The main loop runs while startr + 3735 < highestbin (src/accelsearch.c:168): a
+    spectrum shorter than one block is searched by nobody -- no blocks, no hits, no
+    candidates, no error; the oracle agrees; the pipelined calls work all the same."""
+    N, dt = 6000, 1e-3
+    rng = np.random.default_rng(3)
+    fft = (rng.standard_normal(N // 2) + 1j * rng.standard_normal(N // 2)).astype(np.complex64)
+    s = oracle.Search(fft, N, dt, 20, 8, fhi=1e9, nthreads=2)
+    whits, wcands = s.run()
+    s.close()
+    setup = gpu.configure(fft.size, N, dt, 20, 8, fhi=1e9)
+    assert setup.num_search_blocks == 0 == s.num_blocks and len(whits) == 0 and len(wcands) == 0
+    gpu.load_fft(fft)
+    hits, cands, sig, added = gpu.search()
+    assert len(hits) == 0 and len(cands) == 0
+    gpu.run_launch()
+    gpu.run_launch()
+    assert len(gpu.run_collect()) == 0 and len(gpu.run_collect()) == 0
+    assert len(gpu.search_plane()) == 0
