@@ -289,6 +289,15 @@ template <int R> __device__ __forceinline__ void apply_twiddles_2level(c32 *v, c
 // to start global loads that should fly during passes 2 and 3);
 // store(n, v) receives output n.  Ends with all LDS reads done but no trailing
 // barrier: callers that loop must __syncthreads() before reuse.
+// An 8-byte LDS read that stays one ds_read_b64: left alone, the compiler pairs neighbouring
+// reads into ds_read2_b64, which the LDS serves at half the rate (two accesses of 4 x 16 lanes,
+// 8 cycles per wave-instruction, against 2 cycles for a ds_read_b64).
+__device__ __forceinline__ c32 lds_read(const c32 *p)
+{
+    typedef const volatile c32 __attribute__((address_space(3))) *lds_ptr;
+    return *(lds_ptr) p;
+}
+
 // Phase marker hook of fft3x(): does nothing in product kernels; a diagnostic build passes
 // an object that records the cycle counter at each phase boundary.
 struct NoStamp {
@@ -328,7 +337,7 @@ __device__ __forceinline__ void fft3x(c32 *lds, Load load, Tw1 tw1, Tw2 tw2, Mid
         const int d = g % P::R3, n1 = g / P::R3;
 #pragma unroll
         for (int c = 0; c < P::R2; c++)
-            v[u * P::R2 + c] = lds[n1 * P::S1 + P::R3 * c + d];
+            v[u * P::R2 + c] = lds_read(&lds[n1 * P::S1 + P::R3 * c + d]);
     }
     stamp(4); // first image read (issued)
     __syncthreads(); // every read of image 1 is done before image 2 overwrites it
@@ -353,7 +362,7 @@ __device__ __forceinline__ void fft3x(c32 *lds, Load load, Tw1 tw1, Tw2 tw2, Mid
         const int n1 = g % P::R1, e = g / P::R1;
 #pragma unroll
         for (int d = 0; d < P::R3; d++)
-            v[u * P::R3 + d] = lds[(e * P::R3 + d) * P::S2 + n1];
+            v[u * P::R3 + d] = lds_read(&lds[(e * P::R3 + d) * P::S2 + n1]);
         Dft<P::R3, DIR, SER>::run(&v[u * P::R3]);
 #pragma unroll
         for (int f = 0; f < P::R3; f++)
