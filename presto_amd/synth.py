@@ -117,3 +117,12 @@ def config_fft(name, N=None, seed=None):
     if seed is not None:
         c["seed"] = seed
     return make_fft(c["N"], c["dt"], c["pulsars"], c["seed"]), c
+
+
+def chirp_fft(N, r, z):
+    """Packed spectrum of the noiseless unit-amplitude drifting tone cos(2 pi (r0 u + z u^2 / 2)),
+    u = t/N, r0 = r - z/2: mean Fourier frequency r bins, drift z bins over the series (the
+    signal of the reference's python/ffdot_example.py:8-21).  A filter matched in (r, z)
+    recovers the power N^2/4."""
+    u = np.arange(N, dtype=np.float64) / N
+    return packed_fft(np.cos(2.0 * np.pi * (u * (u * (0.5 * z) + (r - 0.5 * z)))))

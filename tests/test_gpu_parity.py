@@ -368,3 +368,27 @@ def test_series_too_short_for_one_block(gpu, oracle):
     gpu.run_launch()
     assert len(gpu.run_collect()) == 0 and len(gpu.run_collect()) == 0
     assert len(gpu.search_plane()) == 0
+
+
+@pytest.mark.parametrize("zmax,z,r", [(0, 0, 9000.0), (50, 30, 9000.5), (200, -200, 12000.0), (200, 126, 7777.5),
+                                      (300, 300, 9000.0), (1200, -1100, 11000.5)])
+def test_matched_template_recovers_the_tone_power(gpu, zmax, z, r):
+    """Oracle-free known answer, the one of the reference's own demonstration
+    (python/ffdot_example.py:8-26): a noiseless unit-amplitude tone drifting by z bins around
+    mean frequency r puts N^2/4 into the F-Fdot cell (r, z) -- all but the few percent the
+    truncated templates leave out -- and no cell of its block holds more; the search lists
+    it first."""
+    N = 1 << 16
+    fft = synth.chirp_fft(N, r, z)
+    fft[0] = 1.0
+    setup = gpu.configure(fft.size, N, 1e-3, zmax, 1, flo=0.0, fhi=1e9, photon_nph=1.0)
+    gpu.load_fft(fft)
+    startr = setup.rlo + 3735.0 * int((r - setup.rlo) // 3735.0)
+    blk, rlo = gpu.subharm_ffdot_plane(startr)
+    zi, col = (z + zmax) // 2, int(round(2 * (r - rlo)))
+    frac = blk[zi, col] / (N * N / 4.0)
+    assert 0.97 <= frac <= 1.002, frac
+    assert blk.max() <= blk[zi, col] * (1 + 1e-6)
+    hits, cands, sig, added = gpu.search()
+    best = cands[np.argmax(cands["power"])]
+    assert (best["r"], best["z"]) == (r, float(z))

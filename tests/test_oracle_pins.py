@@ -415,3 +415,24 @@ def test_batch_driver_search_flags_match_the_reference_parser(args):
     assert (int(got.locpow), int(got.noharmpolish), int(got.noharmremove)) == \
         (want["locpow"], want["noharmpolish"], want["noharmremove"])
     assert (got.zaplist or "-") == want["zaplist"]
+
+
+@pytest.mark.parametrize("zmax,z,r", [(0, 0, 9000.0), (50, 30, 9000.5), (200, -200, 12000.0), (200, 126, 7777.5),
+                                      (300, 300, 9000.0), (1200, -1100, 11000.5)])
+def test_matched_template_recovers_the_tone_power(oracle, zmax, z, r):
+    """Known answer from the reference's own demonstration (python/ffdot_example.py:8-26:
+    "Fraction of recovered signal power" of a noiseless drifting tone against N^2/4): the F-Fdot
+    cell at the tone's (r, z) holds the whole power, up to what the truncated templates
+    (z_resp_halfwidth, LOWACC) leave out, and no other cell of the block holds more."""
+    from presto_amd import synth
+    N = 1 << 16
+    fft = synth.chirp_fft(N, r, z)
+    fft[0] = 1.0                                  # -photon with one "photon": powers stay raw
+    s = oracle.Search(fft, N, 1e-3, zmax, 1, flo=0.0, fhi=1e9, photon=True, alloc_plane=False)
+    startr = s.rlo + 3735.0 * int((r - s.rlo) // 3735.0)
+    blk, rlo = s.fund_block(startr)
+    zi, col = (z + zmax) // 2, int(round(2 * (r - rlo)))
+    frac = blk[zi, col] / (N * N / 4.0)
+    assert 0.97 <= frac <= 1.002, frac          # 0.979 at half-bin offsets, 0.995-1.0 on the grid
+    assert blk.max() <= blk[zi, col] * (1 + 1e-6)
+    s.close()
