@@ -436,3 +436,25 @@ def test_matched_template_recovers_the_tone_power(oracle, zmax, z, r):
     assert 0.97 <= frac <= 1.002, frac          # 0.979 at half-bin offsets, 0.995-1.0 on the grid
     assert blk.max() <= blk[zi, col] * (1 + 1e-6)
     s.close()
+
+
+def test_search_constants_match_the_reference_header():
+    """ACCEL_USELEN, ACCEL_NUMBETWEEN, ACCEL_DR, ACCEL_DZ, ACCEL_CLOSEST_R as include/accel.h:13-31
+    defines them, read from the header itself when the reference tree is present."""
+    import re
+    hdr = "/root/reference/include/accel.h"
+    if not os.path.exists(hdr):
+        pytest.skip("reference tree absent")
+    text = open(hdr).read()
+    val = lambda name: float(re.search(r"^#define\s+%s\s+([0-9.]+)" % name, text, re.M).group(1))
+    import presto_amd.api as api
+    ours = open(os.path.join(os.path.dirname(HERE), "include", "accelgpu.h")).read()
+    assert int(val("ACCEL_USELEN")) == api.USELEN == int(re.search(r"#define\s+ACCELGPU_USELEN\s+(\d+)", ours).group(1))
+    orc = open(os.path.join(os.path.dirname(HERE), "oracle", "accel_oracle.h")).read()
+    for ref_name, orc_name in (("ACCEL_USELEN", "ORC_USELEN"), ("ACCEL_NUMBETWEEN", "ORC_NUMBETWEEN"),
+                               ("ACCEL_DR", "ORC_DR"), ("ACCEL_RDR", "ORC_RDR"), ("ACCEL_DZ", "ORC_DZ"),
+                               ("ACCEL_RDZ", "ORC_RDZ"), ("ACCEL_CLOSEST_R", "ORC_CLOSEST_R")):
+        assert val(ref_name) == float(re.search(r"#define\s+%s\s+([0-9.]+)" % orc_name, orc).group(1)), ref_name
+    # the product's grid follows from them: columns are half bins (DR), rows step by DZ = 2
+    s = api.plan(1 << 19, 1 << 20, 1e-4, 20, 2, fhi=1e9)
+    assert s.numz == 2 * (20 // int(val("ACCEL_DZ"))) + 1 and s.rlen == (s.highestbin + api.USELEN) * int(val("ACCEL_RDR"))
