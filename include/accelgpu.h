@@ -243,7 +243,10 @@ int accelgpu_search_plane(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hit
 
 /* accelgpu_fill_plane() followed by accelgpu_search_plane().  With a buffer that is too
  * small it returns ACCELGPU_ERR_OVERFLOW and the count in *n_hits, and nothing stays
- * queued: call it again with room for that many. */
+ * queued: call it again with room for that many.  Refused while launches of the
+ * asynchronous pair below are uncollected (so are accelgpu_set_search() and a change of
+ * zmax by accelgpu_build_kernels(): queued trials belong to the geometry they were
+ * launched with). */
 int accelgpu_run(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits, int64_t *n_hits);
 
 /* Asynchronous halves of accelgpu_run() for pipelined batches: _launch queues

@@ -355,10 +355,11 @@ class AccelSearchGPU:
                   photon_nph=0.0, norm_type=0, inmem=True):
         """plan + kernel bank + set_search in one call.  inmem=False selects the
         reference's standard mode (no plane; see run_standard)."""
-        self.setup = plan(numbins, N, dt, zmax, numharm, sigma, flo, fhi, lobin)
-        self.create_subharminfos(self.setup.zmax)
+        setup = plan(numbins, N, dt, zmax, numharm, sigma, flo, fhi, lobin)
+        self.create_subharminfos(setup.zmax)
         fn = self.L.accelgpu_set_search if inmem else self.L.accelgpu_set_search_standard
-        _check(fn(self._h, C.byref(self.setup), int(norm_type), float(photon_nph)))
+        _check(fn(self._h, C.byref(setup), int(norm_type), float(photon_nph)))
+        self.setup = setup                           # only once the library has accepted it
         return self.setup
 
     def set_block_range(self, first_block, num_blocks):

@@ -694,6 +694,9 @@ int resize_slot(accelgpu_ctx *ctx, int i, size_t want)
     sl.cap = 0;
     if (hipMalloc((void **) &sl.d_hits, want * sizeof(DevHit)) != hipSuccess ||
         hipHostMalloc((void **) &sl.h_hits, want * sizeof(DevHit)) != hipSuccess) {
+        if (sl.d_hits) (void) hipFree(sl.d_hits);
+        sl.d_hits = sl.h_hits = nullptr;
+        (void) hipGetLastError();
         set_error("cannot allocate room for %zu hits", want);
         return ACCELGPU_ERR_NOMEM;
     }
@@ -1258,6 +1261,10 @@ int accelgpu_build_kernels(accelgpu_ctx *ctx, int zmax)
         zmax = (zmax / 2 + 1) * 2;
     if (zmax == ctx->zmax)
         return ACCELGPU_OK;
+    if (ctx->inflight > 0) {
+        set_error("accelgpu_build_kernels: collect the %d launched trial(s) first", ctx->inflight);
+        return ACCELGPU_ERR_ARG;
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     drop_graphs(ctx);
     const int numz = (zmax / 2) * 2 + 1;
@@ -1446,6 +1453,10 @@ int set_search_impl(accelgpu_ctx *ctx, const accelgpu_setup *s, int norm_type, f
     if (s->numharmstages < 1 || s->numharmstages > ACCELGPU_MAXSTAGES || s->rlo < 0 ||
         s->highestbin < s->rlo) {
         set_error("accelgpu_set_search: inconsistent setup");
+        return ACCELGPU_ERR_ARG;
+    }
+    if (ctx->inflight > 0) { // their hits are sorted and labelled with the geometry they were launched with
+        set_error("accelgpu_set_search: collect the %d launched trial(s) first", ctx->inflight);
         return ACCELGPU_ERR_ARG;
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1664,6 +1675,7 @@ int accelgpu_fill_plane(accelgpu_ctx *ctx)
     if (rc) return rc;
     if ((rc = check_ready(ctx, true))) return rc;
     if ((rc = need_plane(ctx))) return rc;
+    ctx->plane_serial = 0; // no launched trial's plane any more: a repeat of one regenerates its own
     if ((rc = queue_fill(ctx))) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return ACCELGPU_OK;
@@ -1792,6 +1804,10 @@ int accelgpu_run_collect(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits
 
 int accelgpu_run(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hits, int64_t *n_hits)
 {
+    if (ctx && ctx->inflight > 0) { // the collect below would return the oldest launch, not this one
+        set_error("accelgpu_run: collect the %d launched trial(s) first", ctx->inflight);
+        return ACCELGPU_ERR_ARG;
+    }
     int rc = accelgpu_run_launch(ctx);
     if (rc) return rc;
     rc = accelgpu_run_collect(ctx, hits, max_hits, n_hits);
@@ -1846,8 +1862,9 @@ int accelgpu_fund_block(accelgpu_ctx *ctx, double startr, float *powers, int32_t
 
 // accelgpu_fund_block() for callers that cannot allocate: up to kNoAllocBlocks blocks per
 // call, block spectra and descriptors in this device's `scratch` array, powers into the
-// caller's device buffer.  No hipMalloc/hipFree, no host-device copies, no host wait: the
-// work is queued on the context's stream.  Calls on one GPU share that GPU's array, so
+// caller's device buffer.  No hipMalloc/hipFree, no host-device copies, and no host wait unless
+// an asynchronous upload of the current spectrum is still on its way: the work is queued on
+// the context's stream.  Calls on one GPU share that GPU's array, so
 // calls that overlap in time there (two contexts, two streams) race.
 int accelgpu_fund_blocks_noalloc(accelgpu_ctx *ctx, const double *startr, int32_t nblocks,
                                  float *powers_dev, int32_t *rlo_out)
@@ -1961,6 +1978,7 @@ int accelgpu_fund_to_ffdotplane(accelgpu_ctx *ctx, const float *powers, int32_t 
         set_error("accelgpu_fund_to_ffdotplane: block at rlo=%d does not fit the plane", rlo);
         return ACCELGPU_ERR_ARG;
     }
+    ctx->plane_serial = 0;
     HIPCHK(hipMemcpy2DAsync(ctx->d_plane + col, (size_t) ctx->setup.rlen * sizeof(float), powers,
                             ACCELGPU_USELEN * sizeof(float), ACCELGPU_USELEN * sizeof(float),
                             ctx->numz, hipMemcpyHostToDevice, ctx->stream));
@@ -2012,6 +2030,10 @@ int accelgpu_search_ffdotpows(accelgpu_ctx *ctx, const float *powers, int32_t rl
     const int st = stage_of(numharm);
     if (!powers || !n_hits || (!hits && max_hits > 0) || st < 0 || st >= ctx->setup.numharmstages) {
         set_error("accelgpu_search_ffdotpows: bad arguments (numharm %d)", numharm);
+        return ACCELGPU_ERR_ARG;
+    }
+    if (ctx->inflight > 0) { // the hit buffers hold the launched trials' hits
+        set_error("accelgpu_search_ffdotpows: collect the %d launched trial(s) first", ctx->inflight);
         return ACCELGPU_ERR_ARG;
     }
     const int64_t bcol = (int64_t) rlo * 2;
@@ -2086,6 +2108,7 @@ int accelgpu_put_plane(accelgpu_ctx *ctx, int zind, int64_t col, int64_t count, 
     int rc = use(ctx);
     if (rc) return rc;
     if ((rc = plane_span(ctx, zind, col, count))) return rc;
+    ctx->plane_serial = 0;
     HIPCHK(hipMemcpyAsync(ctx->d_plane + (size_t) zind * ctx->setup.rlen + col, in,
                           (size_t) count * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));

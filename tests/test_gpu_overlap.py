@@ -111,6 +111,12 @@ def test_misuse_is_refused(gpu):
     gpu.run_launch()                                        # specs[1], specs[2] in flight
     with pytest.raises(pa.AccelGPUError):
         gpu.run_launch()                                    # two at most
+    with pytest.raises(pa.AccelGPUError, match="collect the 2 launched"):
+        gpu.run_one_call()                                  # its collect would return specs[1]'s hits
+    with pytest.raises(pa.AccelGPUError, match="collect the 2 launched"):
+        gpu.configure(N // 2, N, DT, ZMAX, NH, fhi=2000.0)  # queued trials belong to their geometry
+    with pytest.raises(pa.AccelGPUError, match="collect the 2 launched"):
+        gpu.create_subharminfos(ZMAX + 10)
     gpu.load_fft(specs[3])                                  # takes the buffer of the collected specs[0]
     with pytest.raises(pa.AccelGPUError):
         gpu.optimize(k0)                                    # its spectrum is gone
