@@ -333,20 +333,23 @@ __global__ __launch_bounds__(P::NT) void k_block_prep(
 // reaches the range check as a large unsigned number; the others share one register per
 // 4096 bytes (never negative) and carry the rest as the instruction's immediate.
 // ---------------------------------------------------------------------------
-template <class P> struct PlaneStore {
+#ifndef BND_VARIANT
+#define BND_VARIANT 0
+#endif
+template <class P, int ES = 4> struct PlaneStore { // ES: bytes per stored element
     static constexpr int NEAR = (P::N < 2048 ? P::N : 2048) / P::NT, NG = P::N >= 1024 ? P::N / 1024 : 1;
     int vnear[NEAR], vgrp[NG];
     __device__ __forceinline__ PlaneStore(int t, int shift)
     {
-        const int voff = (t - shift) * 4;
+        const int voff = (t - shift) * ES;
 #pragma unroll
         for (int i = 0; i < NEAR; i++) {
-            vnear[i] = voff + 4 * P::NT * i;
+            vnear[i] = voff + ES * P::NT * i;
             asm("" : "+v"(vnear[i])); // opaque: the sum must not be split into base + immediate again
         }
 #pragma unroll
         for (int g = 0; g < NG; g++) {
-            vgrp[g] = voff + 4096 * g;
+            vgrp[g] = voff + ES * 1024 * g;
             asm("" : "+v"(vgrp[g]));
         }
     }
@@ -361,10 +364,31 @@ template <class P> struct PlaneStore {
     }
     __device__ __forceinline__ void operator()(__amdgpu_buffer_rsrc_t rsrc, int c, float p) const
     {
+        static_assert(ES == 4, "float elements");
         if (c < 2048)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(p), rsrc, vnear[c / P::NT], 0, 0);
         else
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(p), rsrc, vgrp[c / 1024] + 4 * (c % 1024), 0, 0);
+    }
+    // the 16-bit upper bound of p (see k_harmsum_b)
+    __device__ __forceinline__ void bound(__amdgpu_buffer_rsrc_t rsrc, int c, float p) const
+    {
+        static_assert(ES == 2, "16-bit elements");
+#if BND_VARIANT == 2
+        // the upper half of (bits + 0xFFFF) stored straight from there: no shift
+        const __amdgpu_buffer_rsrc_t r4 = rsrc;
+        const unsigned int b = __float_as_uint(p) + 0xFFFFu;
+        if (c < 2048)
+            asm volatile("buffer_store_short_d16_hi %0, %1, %2, 0 offen" ::"v"(b), "v"(vnear[c / P::NT]), "s"(r4) : "memory");
+        else
+            asm volatile("buffer_store_short_d16_hi %0, %1, %2, 0 offen offset:%3" ::"v"(b), "v"(vgrp[c / 1024]), "s"(r4), "n"(2 * (c % 1024)) : "memory");
+#else
+        const unsigned short b = (unsigned short) ((__float_as_uint(p) + 0xFFFFu) >> 16);
+        if (c < 2048)
+            __builtin_amdgcn_raw_buffer_store_b16(b, rsrc, vnear[c / P::NT], 0, 0);
+        else
+            __builtin_amdgcn_raw_buffer_store_b16(b, rsrc, vgrp[c / 1024] + 2 * (c % 1024), 0, 0);
+#endif
     }
 };
 
@@ -450,12 +474,15 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate(
 //                      then three rows exp(+2*pi*i*b*lo/N), lo = 1..3
 //   pw2: [R2/4+2][R3]  the same for exp(+2*pi*i*d*e/M1)
 // ---------------------------------------------------------------------------
-template <class P, bool KEEPK, int SER, bool ZL = false, class Stamp = afft::NoStamp>
+// BND: every power is stored a second time, rounded up to 16 bits, into `bound`, a plane of
+// the same shape (the harmonic sum reads that one and the float plane only where it matters).
+template <class P, bool KEEPK, int SER, bool ZL = false, class Stamp = afft::NoStamp, bool BND = false>
 __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
     const c32 *__restrict__ bank, const c32 *__restrict__ blockfft,
     const int64_t *__restrict__ blk_col, const int *__restrict__ blk_ncols, int nblk, int chunk,
     float *__restrict__ plane, int64_t rlen, int halfwidth, const c32 *__restrict__ pw1,
-    const c32 *__restrict__ pw2, int numz, int tile_z, int tile_c, Stamp stamp = Stamp())
+    const c32 *__restrict__ pw2, int numz, int tile_z, int tile_c, Stamp stamp = Stamp(),
+    unsigned short *__restrict__ bound = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     c32 *lds = reinterpret_cast<c32 *>(smem);
@@ -520,6 +547,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
     float *prow = plane + (size_t) z * (size_t) rlen;
     const int shift = 2 * halfwidth;
     PlaneStore<P> put(t, shift);
+    PlaneStore<P, 2> put16(t, BND ? shift : 0);
     // every twiddle of passes 1 and 2, formed once and kept in registers for the whole chunk
     c32 W1[P::R1 - 1], W2[P::R2 - 1];
     afft::expand_twiddles<P::R1>(W1, w1);
@@ -540,6 +568,10 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
         const int ncols = blk_ncols[blk];
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, ncols * 4, 0x00020000);
         put.refresh();
+        unsigned short *out16 = BND ? bound + (size_t) (ZL ? it : z) * (size_t) rlen + blk_col[blk] : nullptr;
+        const __amdgpu_buffer_rsrc_t rsrc16 = __builtin_amdgcn_make_buffer_rsrc(out16, 0, BND && BND_VARIANT != 1 ? ncols * 2 : 0, 0x00020000);
+        if constexpr (BND)
+            put16.refresh();
         // launder the pointer: the loads must stay inside the loop (hoisted, they
         // would pin another 2*R1 registers across the whole transform)
         const c32 *krow_l = ZL ? bank + (size_t) it * P::N : krow;
@@ -580,7 +612,13 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
                         dreg[a] = D[P::M1 * a + t];
                 }
             },
-            [&](int n, c32 v) { put(rsrc, n - t, v.x * v.x + v.y * v.y); }, stamp);
+            [&](int n, c32 v) {
+                const float pw = v.x * v.x + v.y * v.y;
+                put(rsrc, n - t, pw);
+                if constexpr (BND)
+                    put16.bound(rsrc16, n - t, pw);
+            },
+            stamp);
         __syncthreads();
         stamp(9);
     }
@@ -754,15 +792,17 @@ __global__ __launch_bounds__(256) void k_harmsum(
 
 
 // ---------------------------------------------------------------------------
-// The one-column-per-thread harmonic sum with the source-column bookkeeping
-// squeezed out of the vector registers, for many harmonics (where registers,
-// not bytes, limit the waves in flight).  Same sums, same order, same hits.
+// Harmonic sum over 16-bit upper bounds, exact only where it can matter.
 //
-// A wave owns 64 consecutive columns rind = R0 + t (R0 wave-uniform, t the lane).
-// For harmonic h/2^s:  (rind*h + 2^(s-1)) >> s  =  Q + ((B + t*h) >> s)  with
-// A = R0*h + 2^(s-1), Q = A >> s, B = A & (2^s - 1): Q is scalar arithmetic done
-// at the moment of a reload, and the lane part is < 64, kept as a byte offset
-// (<= 252) in one byte of a packed register: NH/4 registers instead of NH.
+// `bound` is a second plane of the same shape holding, for every cell, the smallest
+// bfloat16 that is >= the cell's power (bits of the float rounded up to 16).  The kernel
+// walks the columns exactly as k_harmsum does, but reads the bounds: half the bytes.
+// Floating-point addition is monotonic (a <= a', b <= b' => fl(a+b) <= fl(a'+b')), so the
+// sums of the bounds, taken in the same order, bound the exact sums of every stage from
+// above: a row of a wave in which no bound sum crosses its threshold has no crossing.
+// Where one does (a hit, or a cell within 2^-7 of its threshold), the wave recomputes that
+// row from the float plane and compacts the exact crossings: the hits are those of
+// k_harmsum, bit for bit.
 // ---------------------------------------------------------------------------
 constexpr int harm_stage_of(int i) // i-th sub-harmonic in summing order -> its stage s
 {
@@ -776,6 +816,286 @@ constexpr int harm_num_of(int i) // -> its odd numerator h
     const int s = harm_stage_of(i);
     return 2 * (i + 1 - (1 << (s - 1))) + 1;
 }
+__device__ __forceinline__ float bound_value(unsigned short b) { return __uint_as_float((uint32_t) b << 16); }
+__device__ __forceinline__ unsigned short bound_of(float p) { return (unsigned short) ((__float_as_uint(p) + 0xFFFFu) >> 16); }
+
+// bound[i] = bound_of(plane[i]): for planes written by something other than the plane
+// generation kernel (which stores both).
+__global__ __launch_bounds__(256) void k_make_bounds(const float *__restrict__ plane,
+                                                     unsigned short *__restrict__ bound, size_t n)
+{
+    const size_t stride = (size_t) gridDim.x * 256 * 4;
+    for (size_t i = ((size_t) blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n) {
+            const float4 v = *reinterpret_cast<const float4 *>(plane + i);
+            ushort4 b;
+            b.x = bound_of(v.x), b.y = bound_of(v.y), b.z = bound_of(v.z), b.w = bound_of(v.w);
+            *reinterpret_cast<ushort4 *>(bound + i) = b;
+        } else {
+            for (size_t k = i; k < n; k++)
+                bound[k] = bound_of(plane[k]);
+        }
+    }
+}
+
+template <int NSTAGES>
+__global__ __launch_bounds__(256) void k_harmsum_b(
+    const float *__restrict__ plane, const unsigned short *__restrict__ bound, int64_t rlen, int numz,
+    int64_t col0, int64_t ncols, const int64_t *__restrict__ rowoff, const uint32_t *__restrict__ rowchg,
+    HarmParams prm, DevHit *__restrict__ hits, unsigned int *__restrict__ count, unsigned int max_hits,
+    int xcd_remap)
+{
+    constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
+    const int lane = threadIdx.x & 63;
+    unsigned int tile = blockIdx.x;
+    if (xcd_remap) {
+        const unsigned int per = (gridDim.x + 7) / 8;
+        tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+        if ((int64_t) tile * 256 >= ncols)
+            return;
+    }
+    const int64_t c = (int64_t) tile * 256 + threadIdx.x;
+    const bool live = c < ncols;
+    const int64_t rind = col0 + (live ? c : 0); // dead lanes read a valid cell
+    uint32_t off[NHS];                          // byte offset of each source column in a row of bounds
+    {
+        int i = 0;
+#pragma unroll
+        for (int s = 1; s < NSTAGES; s++)
+#pragma unroll
+            for (int h = 1; h < (1 << s); h += 2)
+                off[i++] = (uint32_t) (((rind * h + (1 << (s - 1))) >> s) << 1);
+    }
+    const char *bbytes = reinterpret_cast<const char *>(bound);
+    const char *pbytes = reinterpret_cast<const char *>(plane);
+    uint32_t v[NHS]; // the sources' bounds, 16 bits each
+    for (int zi = 0; zi < numz; zi++) {
+        float p = bound_value(bound[(size_t) zi * (size_t) rlen + rind]);
+        const uint32_t chg = NH > 0 ? rowchg[zi] : 0u;
+        int64_t ro[NHS]; // byte offsets of the source rows in the float plane; half of that in the bounds
+#pragma unroll
+        for (int i = 0; i < NH; i++)
+            ro[i] = rowoff[(size_t) zi * NHS + i];
+        // The column offsets are made opaque once per row: left alone, the compiler adds each of them
+        // to the plane's address outside the loop and keeps 15 64-bit addresses (30 registers)
+        // instead of 15 offsets; this way a load is scalar row address + 32-bit lane offset.
+#pragma unroll
+        for (int i = 0; i < NH; i++)
+            asm volatile("" : "+v"(off[i]));
+#pragma unroll
+        for (int i = 0; i < NH; i++) {
+            if (chg & (1u << i)) {
+                const int64_t r = ro[i] >> 1;
+                // kept as loaded; widened where it is added, so that no branch waits for its load
+                v[i] = *reinterpret_cast<const unsigned short *>(bbytes + r + off[i]);
+            }
+        }
+        bool any = false;
+        {
+            int i = 0;
+#pragma unroll
+            for (int s = 0; s < NSTAGES; s++) {
+                if (s > 0) {
+#pragma unroll
+                    for (int h = 1; h < (1 << s); h += 2)
+                        p += __uint_as_float(v[i++] << 16);
+                }
+                any |= live && (p > prm.powcut[s]);
+            }
+        }
+        if (__ballot(any)) { // rare: this row again, from the float plane
+            float q = plane[(size_t) zi * (size_t) rlen + rind];
+            float ps[NSTAGES];
+            ps[0] = q;
+            // four sources at a time, so that this path's loads do not set the kernel's register count
+#pragma unroll
+            for (int i0 = 0; i0 < NH; i0 += 4) {
+                float e[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (i0 + k < NH) {
+                        // opaque, and tied to the sum so far: twice the offset must not become a register
+                        // per source outside the loop, and a group's loads must not start before the
+                        // group before it has been added
+                        uint32_t o = off[i0 + k];
+                        asm volatile("" : "+v"(o) : "v"(q));
+                        e[k] = *reinterpret_cast<const float *>(pbytes + ro[i0 + k] + (uint32_t) (2u * o)); // a row is < 4 GB
+                    }
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (i0 + k < NH) {
+                        const int i = i0 + k;
+                        q += e[k];
+                        if (((i + 2) & (i + 1)) == 0) // i + 2 a power of two: the last source of its stage
+                            ps[harm_stage_of(i)] = q;
+                    }
+            }
+#pragma unroll
+            for (int s = 0; s < NSTAGES; s++) {
+                const bool hit = live && (ps[s] > prm.powcut[s]);
+                const unsigned long long mask = __ballot(hit);
+                if (mask) {
+                    unsigned int base = 0;
+                    const int leader = __ffsll((long long) mask) - 1;
+                    if (lane == leader)
+                        base = atomicAdd(count, (unsigned int) __popcll(mask));
+                    base = __shfl(base, leader);
+                    if (hit) {
+                        const unsigned int pos = base + (unsigned int) __popcll(mask & ((1ull << lane) - 1ull));
+                        if (pos < max_hits)
+                            hits[pos] = DevHit{ps[s], ((uint32_t) s << 16) | (uint32_t) zi, rind};
+                    }
+                }
+            }
+        }
+    }
+}
+
+// The same with two columns per lane, 64 apart (a wave owns 128 consecutive columns): for
+// harmonic h/2^s the second column's source cell lies exactly 64*h/2^s cells after the
+// first's (an integer for s <= 6), so both columns share one offset register per source and
+// the second load is the first with an immediate offset.  Twice the loads in flight per wave
+// for 15 registers more: the kernel is bound by load latency at full occupancy.
+template <int NSTAGES>
+__global__ __launch_bounds__(256) void k_harmsum_bw(
+    const float *__restrict__ plane, const unsigned short *__restrict__ bound, int64_t rlen, int numz,
+    int64_t col0, int64_t ncols, const int64_t *__restrict__ rowoff, const uint32_t *__restrict__ rowchg,
+    HarmParams prm, DevHit *__restrict__ hits, unsigned int *__restrict__ count, unsigned int max_hits,
+    int xcd_remap)
+{
+    constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
+    const int lane = threadIdx.x & 63;
+    unsigned int tile = blockIdx.x;
+    if (xcd_remap) {
+        const unsigned int per = (gridDim.x + 7) / 8;
+        tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+        if ((int64_t) tile * 512 >= ncols)
+            return;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int64_t c0 = (int64_t) tile * 512 + 128 * wave; // the wave's first column
+    if (c0 >= ncols)
+        return; // nothing to do for the whole wave (the kernel has no barriers)
+    const int64_t R0 = col0 + c0;
+    const bool live0 = c0 + lane < ncols, live1 = c0 + lane + 64 < ncols;
+    // dead lanes read valid cells: the wave's first column, and the plane extends a block past the last searched column
+    const int t = live0 ? lane : 0;
+    const uint32_t toff = 2u * (uint32_t) t; // the lane's byte offset in the wave's 128 bytes of a row of bounds
+    uint32_t off[NHS]; // byte offset of the first column's source cell in a row of bounds
+    {
+        int i = 0;
+#pragma unroll
+        for (int s = 1; s < NSTAGES; s++)
+#pragma unroll
+            for (int h = 1; h < (1 << s); h += 2)
+                off[i++] = (uint32_t) ((((R0 + t) * h + (1 << (s - 1))) >> s) << 1);
+    }
+    const char *bbytes = reinterpret_cast<const char *>(bound);
+    const char *pbytes = reinterpret_cast<const char *>(plane);
+    uint32_t v0[NHS], v1[NHS]; // the sources' bounds, 16 bits each, of the two columns
+    for (int zi = 0; zi < numz; zi++) {
+        const char *frow = bbytes + 2 * ((size_t) zi * (size_t) rlen + (size_t) R0); // scalar
+        const uint32_t f0 = *reinterpret_cast<const unsigned short *>(frow + toff);
+        const uint32_t f1 = *reinterpret_cast<const unsigned short *>(frow + toff + 128);
+        const uint32_t chg = NH > 0 ? rowchg[zi] : 0u;
+        int64_t ro[NHS]; // byte offsets of the source rows in the float plane; half of that in the bounds
+#pragma unroll
+        for (int i = 0; i < NH; i++)
+            ro[i] = rowoff[(size_t) zi * NHS + i];
+        // opaque once per row: a load is then scalar row address + 32-bit lane offset, not one of
+        // 15 64-bit addresses kept in registers
+#pragma unroll
+        for (int i = 0; i < NH; i++)
+            asm volatile("" : "+v"(off[i]));
+#pragma unroll
+        for (int i = 0; i < NH; i++) {
+            if (chg & (1u << i)) {
+                const int s = harm_stage_of(i), h = harm_num_of(i);
+                const char *src = bbytes + (ro[i] >> 1) + off[i];
+                v0[i] = *reinterpret_cast<const unsigned short *>(src);
+                v1[i] = *reinterpret_cast<const unsigned short *>(src + 2 * ((64 * h) >> s));
+            }
+        }
+        float p0 = __uint_as_float(f0 << 16), p1 = __uint_as_float(f1 << 16);
+        bool any = false;
+        {
+            int i = 0;
+#pragma unroll
+            for (int s = 0; s < NSTAGES; s++) {
+                if (s > 0) {
+#pragma unroll
+                    for (int h = 1; h < (1 << s); h += 2) {
+                        p0 += __uint_as_float(v0[i] << 16);
+                        p1 += __uint_as_float(v1[i] << 16);
+                        i++;
+                    }
+                }
+                any |= (live0 && (p0 > prm.powcut[s])) | (live1 && (p1 > prm.powcut[s]));
+            }
+        }
+        if (__ballot(any)) { // rare: this row again, from the float plane, one column after the other
+#pragma unroll 1
+            for (int k = 0; k < 2; k++) {
+                const bool live = k ? live1 : live0;
+                const int64_t rind = R0 + t + 64 * k;
+                float q = plane[(size_t) zi * (size_t) rlen + rind];
+                float ps[NSTAGES];
+                ps[0] = q;
+#pragma unroll
+                for (int i0 = 0; i0 < NH; i0 += 4) {
+                    float e[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (i0 + j < NH) {
+                            // tied to the sum so far: a group's loads start when the group before is added
+                            const int sI = harm_stage_of(i0 + j), hI = harm_num_of(i0 + j); // constants once unrolled
+                            uint32_t o = off[i0 + j];
+                            asm volatile("" : "+v"(o) : "v"(q));
+                            o = 2u * o + (k ? 4u * (uint32_t) ((64 * hI) >> sI) : 0u); // a row is < 4 GB
+                            e[j] = *reinterpret_cast<const float *>(pbytes + ro[i0 + j] + o);
+                        }
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (i0 + j < NH) {
+                            const int i = i0 + j;
+                            q += e[j];
+                            if (((i + 2) & (i + 1)) == 0) // the last source of its stage
+                                ps[harm_stage_of(i)] = q;
+                        }
+                }
+#pragma unroll
+                for (int s = 0; s < NSTAGES; s++) {
+                    const bool hit = live && (ps[s] > prm.powcut[s]);
+                    const unsigned long long mask = __ballot(hit);
+                    if (mask) {
+                        unsigned int base = 0;
+                        const int leader = __ffsll((long long) mask) - 1;
+                        if (lane == leader)
+                            base = atomicAdd(count, (unsigned int) __popcll(mask));
+                        base = __shfl(base, leader);
+                        if (hit) {
+                            const unsigned int pos = base + (unsigned int) __popcll(mask & ((1ull << lane) - 1ull));
+                            if (pos < max_hits)
+                                hits[pos] = DevHit{ps[s], ((uint32_t) s << 16) | (uint32_t) zi, rind};
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The one-column-per-thread harmonic sum with the source-column bookkeeping
+// squeezed out of the vector registers, for many harmonics (where registers,
+// not bytes, limit the waves in flight).  Same sums, same order, same hits.
+//
+// A wave owns 64 consecutive columns rind = R0 + t (R0 wave-uniform, t the lane).
+// For harmonic h/2^s:  (rind*h + 2^(s-1)) >> s  =  Q + ((B + t*h) >> s)  with
+// A = R0*h + 2^(s-1), Q = A >> s, B = A & (2^s - 1): Q is scalar arithmetic done
+// at the moment of a reload, and the lane part is < 64, kept as a byte offset
+// (<= 252) in one byte of a packed register: NH/4 registers instead of NH.
+// ---------------------------------------------------------------------------
 
 template <int NSTAGES, bool DUMP>
 __global__ __launch_bounds__(256) void k_harmsum_lean(

@@ -105,6 +105,8 @@ struct Tuning {
     int std_blocks = 0;     // standard mode: search blocks per pass; 0: as many as the scratch holds
     int opt_nt = 512;       // candidate optimisation: threads per workgroup
     int use_graph = 1;      // small searches: one captured graph per launch instead of nine stream operations
+    int hs_bound = 1;       // harmonic sum over 16-bit upper bounds of the plane, exact where a bound crosses
+                            // (0: off, float plane only; 1: on; 2 / 3: on, one / two columns per lane forced)
 };
 
 struct accelgpu_ctx {
@@ -175,6 +177,9 @@ struct accelgpu_ctx {
     size_t blockfft_cap = 0;
     float *d_plane = nullptr;
     size_t plane_cap = 0;
+    unsigned short *d_bound = nullptr; // 16-bit upper bounds of the plane's cells (see k_harmsum_b)
+    size_t bound_cap = 0;
+    bool bound_stale = true;           // some plane cell was written without its bound
     int64_t *d_rowoff = nullptr; // [numz][NH] byte offsets of the sub-harmonic source rows
     size_t rowoff_cap = 0;
     uint32_t *d_rowchg = nullptr; // [numz] bit i: source row of harmonic i differs from row zi-1
@@ -267,6 +272,7 @@ struct accelgpu_ctx {
 namespace {
 
 void free_subbanks(accelgpu_ctx *ctx);
+int reserve_bounds(accelgpu_ctx *ctx);
 
 int use(accelgpu_ctx *ctx)
 {
@@ -520,8 +526,10 @@ dim3 corr_grid(const Tuning &tn, int numz, int nchunks, int *tile_z, int *tile_c
     return dim3((unsigned) (((tiles + 7) / 8) * 8 * tz * tc));
 }
 
+// d_bound (optional): a second plane of the shape of d_plane that receives the 16-bit upper
+// bound of every power stored (register form only; see k_harmsum_b).
 int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const int64_t *d_col,
-                     const int *d_ncols, float *d_plane, int64_t rlen)
+                     const int *d_ncols, float *d_plane, int64_t rlen, unsigned short *d_bound = nullptr)
 {
     // Register-resident twiddle form for both plans (measured on one device: 3.3 against
     // 5.8 ms per 2^23-point zmax 200 search, 83 against 116 ms per 2^24-point zmax 1200
@@ -554,17 +562,20 @@ int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const i
     } else {
         rgrid = corr_grid(tn, ctx->numz, (int) grid.y, &tile_z, &tile_c);
     }
-#define LAUNCH_RR(PLAN, ZL)                                                                    \
-    hipLaunchKernelGGL((accelk::k_correlate_rr<PLAN, false, 16, ZL>), rgrid, dim3(PLAN::NT),   \
+#define LAUNCH_RR(PLAN, ZL, BND)                                                               \
+    hipLaunchKernelGGL((accelk::k_correlate_rr<PLAN, false, 16, ZL, afft::NoStamp, BND>), rgrid, dim3(PLAN::NT),   \
                        PLAN::LDS_BYTES + std::min(std::max(tn.corr_lds, 0), 20000), ctx->stream, ctx->d_bank, d_blockfft, d_col, d_ncols,   \
                        nblk, chunk, d_plane, rlen, ctx->halfwidth, ctx->pw_inv.pw1,            \
-                       ctx->pw_inv.pw2, ctx->numz, tile_z, tile_c)
-    if (rr && ctx->fftlen == 8192) {
-        if (zl) LAUNCH_RR(P8K, true);
-        else LAUNCH_RR(P8K, false);
+                       ctx->pw_inv.pw2, ctx->numz, tile_z, tile_c, afft::NoStamp(), d_bound)
+    if (rr && zl && d_bound) {
+        if (ctx->fftlen == 8192) LAUNCH_RR(P8K, true, true);
+        else LAUNCH_RR(P16K, true, true);
+    } else if (rr && ctx->fftlen == 8192) {
+        if (zl) LAUNCH_RR(P8K, true, false);
+        else LAUNCH_RR(P8K, false, false);
     } else if (rr) {
-        if (zl) LAUNCH_RR(P16K, true);
-        else LAUNCH_RR(P16K, false);
+        if (zl) LAUNCH_RR(P16K, true, false);
+        else LAUNCH_RR(P16K, false, false);
 #undef LAUNCH_RR
     } else if (ctx->fftlen == 8192) {
         hipLaunchKernelGGL((accelk::k_correlate<P8K, false>), grid, dim3(P8K::NT), P8K::LDS_BYTES,
@@ -577,6 +588,12 @@ int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const i
     }
     HIPCHK(hipGetLastError());
     return prof_end(ctx, 1, &ep);
+}
+
+// Does the harmonic sum of this search read the 16-bit bounds (k_harmsum_b)?
+bool bounds_in_use(const accelgpu_ctx *ctx)
+{
+    return ctx->tune.hs_bound && ctx->d_bound && ctx->inmem && ctx->setup.numharmstages <= 5;
 }
 
 // Where a harmonic-sum launch compacts its threshold crossings.
@@ -658,6 +675,60 @@ int launch_harmsum(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, 
     // (measured on the 2^23-point, zmax 200 plane: 1-2 harmonics 80/78 % of the HBM peak
     // with two pairs against 44/49 % with one column; 4 harmonics 71.5 % with one pair
     // against 60.7 %; 8 harmonics 75 % with one column against 66 % with pairs)
+    if constexpr (!DUMP) {
+        if (bounds_in_use(ctx) && nstages == ctx->setup.numharmstages) {
+            if (ctx->bound_stale) { // the plane was written without its bounds: all of them afresh
+                const size_t n = (size_t) ctx->setup.rlen * ctx->numz;
+                hipLaunchKernelGGL(accelk::k_make_bounds, dim3(256 * 16), dim3(256), 0, ctx->stream, ctx->d_plane,
+                                   ctx->d_bound, n);
+                HIPCHK(hipGetLastError());
+                ctx->bound_stale = false;
+            }
+            accelk::HarmParams prm;
+            for (int i = 0; i < 6; i++)
+                prm.powcut[i] = i < ctx->setup.numharmstages ? ctx->setup.powcut[i] : INFINITY;
+            const int remap = ctx->tune.hs_xcd_remap ? 1 : 0;
+            unsigned ntiles = (unsigned) ((ncols + 255) / 256);
+            if (remap)
+                ntiles = ((ntiles + 7) / 8) * 8;
+            const unsigned int cap = (unsigned int) std::min<size_t>(out.cap, 0xFFFFFFFFu);
+            EventPair ep;
+            if (timed) {
+                int rc = prof_begin(ctx, 2, &ep);
+                if (rc) return rc;
+            }
+#define LAUNCH_HSB(NS)                                                                                    \
+    hipLaunchKernelGGL((accelk::k_harmsum_b<NS>), dim3(ntiles), dim3(256), ctx->tune.hs_lds, ctx->stream, \
+                       ctx->d_plane, ctx->d_bound, ctx->setup.rlen, ctx->numz, col0, ncols, ctx->d_rowoff, \
+                       ctx->d_rowchg, prm, out.hits, out.count, cap, remap)
+#define LAUNCH_HSBW(NS)                                                                                    \
+    hipLaunchKernelGGL((accelk::k_harmsum_bw<NS>), dim3(ntiles2), dim3(256), ctx->tune.hs_lds, ctx->stream, \
+                       ctx->d_plane, ctx->d_bound, ctx->setup.rlen, ctx->numz, col0, ncols, ctx->d_rowoff, \
+                       ctx->d_rowchg, prm, out.hits, out.count, cap, remap)
+            unsigned ntiles2 = (unsigned) ((ncols + 511) / 512);
+            if (remap)
+                ntiles2 = ((ntiles2 + 7) / 8) * 8;
+            // Two columns per lane (twice the loads in flight) once there are enough columns to fill the
+            // device with half as many workgroups: 2^23 points, zmax 200, 16 harmonics 3.49 against 4.2 ms,
+            // 8 harmonics 2.03 against 2.95 ms; 2^21 points, zmax 50 0.315 against 0.245 ms.
+            // hs_bound = 2 / 3 force the one-column / the two-column kernel.
+            const bool wide = ctx->tune.hs_bound == 3 ||
+                              (ctx->tune.hs_bound == 1 && nstages >= 4 && ncols >= ((int64_t) 1 << 22));
+            switch (nstages) {
+            case 1: if (wide) LAUNCH_HSBW(1); else LAUNCH_HSB(1); break;
+            case 2: if (wide) LAUNCH_HSBW(2); else LAUNCH_HSB(2); break;
+            case 3: if (wide) LAUNCH_HSBW(3); else LAUNCH_HSB(3); break;
+            case 4: if (wide) LAUNCH_HSBW(4); else LAUNCH_HSB(4); break;
+            default: if (wide) LAUNCH_HSBW(5); else LAUNCH_HSB(5); break;
+            }
+#undef LAUNCH_HSB
+#undef LAUNCH_HSBW
+            HIPCHK(hipGetLastError());
+            if (timed)
+                return prof_end(ctx, 2, &ep);
+            return ACCELGPU_OK;
+        }
+    }
     int j = nstages <= 2 ? 2 : nstages == 3 ? 1 : 0;
     if (ctx->tune.hs_j >= 0)
         j = ctx->tune.hs_j;
@@ -784,8 +855,13 @@ int queue_fill(accelgpu_ctx *ctx)
     int rc = launch_block_prep(ctx, ctx->nblk_active, ctx->d_blk_lobin, ctx->d_blk_numdata,
                                ctx->d_blockfft);
     if (rc) return rc;
-    return launch_correlate(ctx, ctx->nblk_active, ctx->d_blockfft, ctx->d_blk_col,
-                            ctx->d_blk_ncols, ctx->d_plane, ctx->setup.rlen);
+    // the bounds are written along with the powers by the register form that loops over
+    // templates; any other way of filling the plane leaves them behind
+    const bool with_bounds = bounds_in_use(ctx) && ctx->tune.corr_rr != 0 && ctx->tune.corr_zl != 0;
+    if (!with_bounds)
+        ctx->bound_stale = true;
+    return launch_correlate(ctx, ctx->nblk_active, ctx->d_blockfft, ctx->d_blk_col, ctx->d_blk_ncols,
+                            ctx->d_plane, ctx->setup.rlen, with_bounds ? ctx->d_bound : nullptr);
 }
 
 // Plane generation and harmonic sum of one whole trial, chunk by chunk in ascending r: the
@@ -800,8 +876,12 @@ int queue_fill_and_sum_chunked(accelgpu_ctx *ctx, int chunk_blocks, const HitTar
     for (int s0 = 0; s0 < ctx->nsearch; s0 += chunk_blocks) {
         const int s1 = std::min(s0 + chunk_blocks, ctx->nsearch);
         const int b0 = s0 == 0 ? 0 : ctx->nprepop + s0, b1 = ctx->nprepop + s1; // pre-population blocks go first
+        const bool with_bounds = bounds_in_use(ctx) && ctx->tune.corr_rr != 0 && ctx->tune.corr_zl != 0;
+        if (!with_bounds)
+            ctx->bound_stale = true;
         if ((rc = launch_correlate(ctx, b1 - b0, ctx->d_blockfft + (size_t) b0 * nf, ctx->d_blk_col + b0,
-                                   ctx->d_blk_ncols + b0, ctx->d_plane, ctx->setup.rlen)))
+                                   ctx->d_blk_ncols + b0, ctx->d_plane, ctx->setup.rlen,
+                                   with_bounds ? ctx->d_bound : nullptr)))
             return rc;
         if ((rc = launch_harmsum<false>(ctx, ctx->setup.numharmstages, ctx->col0 + (int64_t) s0 * ACCELGPU_USELEN,
                                         (int64_t) (s1 - s0) * ACCELGPU_USELEN, nullptr, 0, out)))
@@ -978,6 +1058,7 @@ const TuneName kTuneNames[] = {
     {"hs_j", &Tuning::hs_j},                 {"hs_chunk_blocks", &Tuning::hs_chunk_blocks},
     {"std_table", &Tuning::std_table},       {"std_blocks", &Tuning::std_blocks},
     {"opt_nt", &Tuning::opt_nt},             {"use_graph", &Tuning::use_graph},
+    {"hs_bound", &Tuning::hs_bound},
 };
 
 void tuning_from_env(Tuning *t)
@@ -1109,6 +1190,8 @@ int accelgpu_create(accelgpu_ctx **out, int device)
     if ((rc = allow_lds(accelk::k_correlate_rr<P8K, false, 16, true>, P8K::LDS_BYTES + 20000))) return rc;
     if ((rc = allow_lds(accelk::k_correlate_rr<P16K, false, 16, false>, P16K::LDS_BYTES + 20000))) return rc;
     if ((rc = allow_lds(accelk::k_correlate_rr<P16K, false, 16, true>, P16K::LDS_BYTES + 20000))) return rc;
+    if ((rc = allow_lds(accelk::k_correlate_rr<P8K, false, 16, true, afft::NoStamp, true>, P8K::LDS_BYTES + 20000))) return rc;
+    if ((rc = allow_lds(accelk::k_correlate_rr<P16K, false, 16, true, afft::NoStamp, true>, P16K::LDS_BYTES + 20000))) return rc;
     if ((rc = allow_lds(accelk::k_fft_rows<P8K, -1>, P8K::LDS_BYTES))) return rc;
     if ((rc = allow_lds(accelk::k_fft_rows<P16K, -1>, P16K::LDS_BYTES))) return rc;
     if ((rc = allow_lds(speck::k_bigfft_cols<P8K>, P8K::LDS_BYTES))) return rc;
@@ -1139,7 +1222,7 @@ void accelgpu_destroy(accelgpu_ctx *ctx)
     void *dev[] = {ctx->pw_inv.pw1, ctx->pw_inv.pw2, ctx->d_bank, ctx->tw_inv.tw1, ctx->tw_inv.tw2, ctx->tw_fwd_full.tw1,
                    ctx->tw_fwd_full.tw2, ctx->tw_fwd_half.tw1, ctx->tw_fwd_half.tw2,
                    ctx->d_own[0], ctx->d_own[1], ctx->d_own[2], ctx->d_blk_lobin, ctx->d_blk_col, ctx->d_blk_numdata,
-                   ctx->d_blk_ncols, ctx->d_blockfft, ctx->d_plane, ctx->d_rowoff, ctx->d_rowchg, ctx->d_tmp, ctx->d_one_lobin, ctx->d_one_col,
+                   ctx->d_blk_ncols, ctx->d_blockfft, ctx->d_plane, ctx->d_bound, ctx->d_rowoff, ctx->d_rowchg, ctx->d_tmp, ctx->d_one_lobin, ctx->d_one_col,
                    ctx->d_one_numdata, ctx->d_one_ncols, ctx->d_one_blockfft};
     for (void *p : dev)
         if (p) (void) hipFree(p);
@@ -1199,6 +1282,8 @@ int accelgpu_set_tuning(accelgpu_ctx *ctx, const char *name, int value)
         if (!strcmp(name, k.name)) {
             ctx->tune.*(k.field) = value;
             drop_graphs(ctx);
+            if (k.field == &Tuning::hs_bound && value && ctx->have_search && ctx->inmem)
+                return reserve_bounds(ctx);
             return ACCELGPU_OK;
         }
     set_error("accelgpu_set_tuning: no knob named '%s'", name);
@@ -1434,6 +1519,32 @@ int accelgpu_load_fft_device(accelgpu_ctx *ctx, const void *dev, int64_t numbins
 
 namespace {
 
+// The plane of 16-bit bounds beside the float plane, when the knob asks for it and the
+// memory is there (half the plane again).  Without it the harmonic sum reads the float
+// plane alone: same hits.
+int reserve_bounds(accelgpu_ctx *ctx)
+{
+    const size_t plane_elems = (size_t) ctx->setup.rlen * ctx->numz;
+    if (!ctx->tune.hs_bound || !ctx->d_plane || plane_elems == 0 || ctx->setup.numharmstages > 5)
+        return ACCELGPU_OK;
+    if (ctx->bound_cap >= plane_elems && ctx->d_bound)
+        return ACCELGPU_OK;
+    if (ctx->d_bound) HIPCHK(hipFree(ctx->d_bound));
+    ctx->d_bound = nullptr;
+    ctx->bound_cap = 0;
+    ctx->bound_stale = true;
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    const size_t want = plane_elems * sizeof(unsigned short) + 64; // the two-column kernel reads 2 bytes past a cell
+    if (want + ((size_t) 4 << 30) > free_b || hipMalloc((void **) &ctx->d_bound, want) != hipSuccess) {
+        (void) hipGetLastError();
+        ctx->d_bound = nullptr; // not an error: the search runs from the float plane
+        return ACCELGPU_OK;
+    }
+    ctx->bound_cap = plane_elems;
+    return ACCELGPU_OK;
+}
+
 int set_search_impl(accelgpu_ctx *ctx, const accelgpu_setup *s, int norm_type, float nph, bool inmem)
 {
     int rc = use(ctx);
@@ -1526,6 +1637,11 @@ int set_search_impl(accelgpu_ctx *ctx, const accelgpu_setup *s, int norm_type, f
             ctx->d_plane = nullptr;
             ctx->plane_cap = 0;
         }
+        if (ctx->d_bound) {
+            HIPCHK(hipFree(ctx->d_bound));
+            ctx->d_bound = nullptr;
+            ctx->bound_cap = 0;
+        }
         ctx->have_search = true;
         return ACCELGPU_OK;
     }
@@ -1560,6 +1676,9 @@ int set_search_impl(accelgpu_ctx *ctx, const accelgpu_setup *s, int norm_type, f
         return rc;
     if (fresh || !same_geometry)
         HIPCHK(hipMemsetAsync(ctx->d_plane, 0, plane_elems * sizeof(float), ctx->stream));
+    if ((rc = reserve_bounds(ctx))) return rc;
+    if (fresh || !same_geometry)
+        ctx->bound_stale = true; // the first search renews them all (cells nothing writes are part of the plane)
 
     // sub-harmonic source rows, in summing order (stage ascending, odd harmonic
     // ascending), as byte offsets into the plane: [numz][nh]
@@ -1728,8 +1847,10 @@ int accelgpu_run_launch(accelgpu_ctx *ctx)
         if ((rc = spectrum_ready(ctx, ctx->stream))) return rc;
         const bool whole_grid = ctx->nblk_active == ctx->nblk && ctx->range_first == 0 && ctx->range_count == ctx->nsearch;
         const bool small = ctx->setup.plane_bytes <= ((int64_t) 64 << 20);
+        // (a plane whose bounds are out of date takes the plain path once: the pass that renews
+        // them must not become part of a captured launch)
         if (ctx->tune.use_graph && small && whole_grid && ctx->tune.hs_chunk_blocks == 0 && !ctx->profiling &&
-            ctx->stream == ctx->own_stream) {
+            ctx->stream == ctx->own_stream && !(bounds_in_use(ctx) && ctx->bound_stale)) {
             if ((rc = launch_as_graph(ctx, si))) return rc;
             ctx->plane_serial = sl.serial;
             sl.prefetch = prefetch_hits(ctx, sl);
@@ -1979,6 +2100,7 @@ int accelgpu_fund_to_ffdotplane(accelgpu_ctx *ctx, const float *powers, int32_t 
         return ACCELGPU_ERR_ARG;
     }
     ctx->plane_serial = 0;
+    ctx->bound_stale = true;
     HIPCHK(hipMemcpy2DAsync(ctx->d_plane + col, (size_t) ctx->setup.rlen * sizeof(float), powers,
                             ACCELGPU_USELEN * sizeof(float), ACCELGPU_USELEN * sizeof(float),
                             ctx->numz, hipMemcpyHostToDevice, ctx->stream));
@@ -2109,6 +2231,7 @@ int accelgpu_put_plane(accelgpu_ctx *ctx, int zind, int64_t col, int64_t count, 
     if (rc) return rc;
     if ((rc = plane_span(ctx, zind, col, count))) return rc;
     ctx->plane_serial = 0;
+    ctx->bound_stale = true;
     HIPCHK(hipMemcpyAsync(ctx->d_plane + (size_t) zind * ctx->setup.rlen + col, in,
                           (size_t) count * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
