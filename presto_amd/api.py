@@ -362,6 +362,14 @@ class AccelSearchGPU:
         self.setup = setup                           # only once the library has accepted it
         return self.setup
 
+    def set_search(self, setup, norm_type=0, photon_nph=0.0, inmem=True):
+        """accelgpu_set_search() with a set-up the caller filled or changed (thresholds of its
+        own, say); the kernel bank for setup.zmax must exist (create_subharminfos)."""
+        fn = self.L.accelgpu_set_search if inmem else self.L.accelgpu_set_search_standard
+        _check(fn(self._h, C.byref(setup), int(norm_type), float(photon_nph)))
+        self.setup = setup
+        return self.setup
+
     def set_block_range(self, first_block, num_blocks):
         """Search only blocks [first, first+num) of the grid (one long series split
         over GPUs).  Returns the number of plane blocks a fill will generate."""

@@ -1,0 +1,163 @@
+"""The harmonic sum over the plane's 16-bit upper bounds (k_harmsum_b / k_harmsum_bw) against
+the plain sum over the float plane (k_harmsum): the two must return the same hits bit for bit
+on every geometry, through every way the plane can be written, and at the values where a
+rounded-up 16-bit bound behaves specially (equal to its power, overflowing to infinity).
+The plain sum itself is checked against the CPU oracle in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import presto_amd as pa
+from presto_amd import synth
+from presto_amd.api import plan
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    g = pa.AccelSearchGPU(0)
+    yield g
+    g.set_tuning("hs_bound", 1)
+    g.close()
+
+
+def _hits_by_mode(gpu, modes=(0, 1, 2, 3), max_hits=1 << 22, call=None):
+    out = {}
+    for m in modes:
+        gpu.set_tuning("hs_bound", m)
+        out[m] = (call or gpu.run)(max_hits=max_hits)
+    return out
+
+
+def _configure_with_thresholds(gpu, numbins, N, dt, zmax, numharm, powcut, **kw):
+    """A search whose thresholds are set by hand (so that a test decides how many cells cross)."""
+    setup = plan(numbins, N, dt, zmax, numharm, **kw)
+    for s in range(setup.numharmstages):
+        setup.powcut[s] = powcut[s] if hasattr(powcut, "__len__") else powcut * (s + 1)
+    gpu.create_subharminfos(setup.zmax)
+    return gpu.set_search(setup)
+
+
+def _assert_same(res):
+    ref = res[0]
+    for m, h in res.items():
+        assert len(h) == len(ref) and h.tobytes() == ref.tobytes(), "hs_bound=%d differs from the float-plane sum" % m
+
+
+@pytest.mark.parametrize("numharm", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("zmax", [0, 20, 200])
+def test_same_hits_for_every_number_of_harmonics(gpu, numharm, zmax):
+    N, dt = 1 << 20, 1e-4
+    fft = synth.make_fft(N, dt, [dict(f=123.456, z=3.0, amp=0.3, duty=0.08), dict(f=741.0, z=-9.0, amp=0.2, duty=0.05)],
+                         seed=300 + numharm)
+    gpu.configure(N // 2, N, dt, zmax, numharm, sigma=1.5, fhi=4000.0)
+    gpu.load_fft(fft)
+    res = _hits_by_mode(gpu)
+    assert len(res[0]) > 50           # a low threshold: many rows take the exact path
+    _assert_same(res)
+
+
+def test_ragged_end_and_odd_geometry(gpu):
+    """A search whose column count is not a multiple of the kernels' tiles (dead lanes in the
+    last wave, the second column of a lane beyond the last searched one) and that starts high."""
+    N, dt = 1 << 19, 1e-4
+    fft = synth.noise_fft(N // 2, 77)
+    _configure_with_thresholds(gpu, N // 2, N, dt, 10, 8, [9.0, 12.0, 17.0, 26.0], flo=37.0, fhi=1913.0)
+    gpu.load_fft(fft)
+    res = _hits_by_mode(gpu)
+    assert len(res[0]) > 300
+    _assert_same(res)
+
+
+def test_dense_hits(gpu):
+    """A threshold so low that most rows of most waves cross it: the exact path is the common one."""
+    N, dt = 1 << 18, 1e-4
+    fft = synth.noise_fft(N // 2, 78)
+    _configure_with_thresholds(gpu, N // 2, N, dt, 6, 16, [2.5, 4.0, 7.0, 12.0, 21.0], fhi=2000.0)
+    gpu.load_fft(fft)
+    res = _hits_by_mode(gpu, max_hits=1 << 24)
+    assert len(res[0]) > 200000
+    _assert_same(res)
+
+
+def test_plane_written_by_the_host_renews_the_bounds(gpu):
+    """put_plane / fund_to_ffdotplane change float cells without their bounds: the next search
+    must notice (it renews all bounds first) -- planted powers far above every threshold, at
+    values whose 16-bit bound equals the power (1024.0), overflows to infinity (3.3e38) or sits
+    one float below a bound (nextafter(2048, 0))."""
+    N, dt = 1 << 19, 1e-4
+    fft = synth.noise_fft(N // 2, 79)
+    setup = gpu.configure(N // 2, N, dt, 20, 16, sigma=6.0, fhi=2000.0)
+    gpu.load_fft(fft)
+    gpu.set_tuning("hs_bound", 1)
+    gpu.fill_plane()
+    before = gpu.search_plane()
+    col0 = 2 * setup.rlo
+    plant = {(3, col0 + 7470 * 2 + 11): np.float32(1024.0),
+             (10, col0 + 7470 * 5 + 4001): np.float32(3.3e38),
+             (17, col0 + 7470 * 9 + 64): np.nextafter(np.float32(2048.0), np.float32(0.0))}
+    for (zi, col), val in plant.items():
+        gpu.put_plane(zi, col, np.array([val], dtype=np.float32))
+    res = _hits_by_mode(gpu, call=gpu.search_plane)
+    _assert_same(res)
+    got = {(int(h["zind"]), int(h["rind"])): h["power"] for h in res[1] if h["stage"] == 0}
+    for key, val in plant.items():
+        assert key in got and got[key] == val
+    assert len(res[1]) > len(before)
+
+
+def test_block_range_and_chunked_sum(gpu):
+    N, dt = 1 << 21, 1e-4
+    fft = synth.make_fft(N, dt, [dict(f=200.2, z=5.0, amp=0.3, duty=0.1)], seed=81)
+    setup = gpu.configure(N // 2, N, dt, 20, 8, sigma=2.0, fhi=4900.0)
+    gpu.load_fft(fft)
+    whole = _hits_by_mode(gpu)
+    _assert_same(whole)
+    nb = setup.num_search_blocks
+    try:
+        gpu.set_block_range(nb // 3, nb // 2)
+        part = _hits_by_mode(gpu)
+        _assert_same(part)
+        want = whole[0][(whole[0]["block"] >= nb // 3) & (whole[0]["block"] < nb // 3 + nb // 2)]
+        assert part[0].tobytes() == want.tobytes()
+    finally:
+        gpu.set_block_range(0, nb)
+    try:
+        gpu.set_tuning("hs_chunk_blocks", 40)
+        chunked = _hits_by_mode(gpu)
+        _assert_same(chunked)
+        assert chunked[1].tobytes() == whole[0].tobytes()
+    finally:
+        gpu.set_tuning("hs_chunk_blocks", 0)
+
+
+def test_table_form_fill_leaves_no_stale_bounds(gpu):
+    """The table-form plane generation (corr_rr = 0) does not store bounds: a bounded search
+    after it renews them; and switching the bounds off and on again between trials with
+    different spectra must not reuse the first trial's bounds."""
+    N, dt = 1 << 20, 1e-4
+    a = synth.make_fft(N, dt, [dict(f=150.0, z=2.0, amp=0.3, duty=0.1)], seed=82)
+    b = synth.make_fft(N, dt, [dict(f=333.3, z=-6.0, amp=0.3, duty=0.1)], seed=83)
+    gpu.configure(N // 2, N, dt, 20, 16, sigma=2.0, fhi=4000.0)
+    gpu.set_tuning("hs_bound", 0)
+    gpu.load_fft(a)
+    want_a = gpu.run()
+    gpu.load_fft(b)
+    want_b = gpu.run()
+    assert want_a.tobytes() != want_b.tobytes()
+    gpu.set_tuning("hs_bound", 1)
+    gpu.load_fft(a)
+    assert gpu.run().tobytes() == want_a.tobytes()
+    gpu.set_tuning("hs_bound", 0)
+    gpu.load_fft(b)
+    gpu.run()                                   # float plane now holds b, the bounds still a
+    gpu.set_tuning("hs_bound", 1)
+    assert gpu.search_plane().tobytes() == want_b.tobytes()
+    try:
+        gpu.set_tuning("corr_rr", 0)            # (another transform kernel: powers differ in the last bits)
+        gpu.load_fft(a)
+        got = gpu.run()
+        gpu.set_tuning("hs_bound", 0)
+        assert got.tobytes() == gpu.run().tobytes()
+    finally:
+        gpu.set_tuning("corr_rr", 1)
