@@ -365,6 +365,18 @@ template <class P, int ES = 4> struct PlaneStore { // ES: bytes per stored eleme
     __device__ __forceinline__ void operator()(__amdgpu_buffer_rsrc_t rsrc, int c, float p) const
     {
         static_assert(ES == 4, "float elements");
+#if BND_VARIANT == 3
+        // timing only: half as many store instructions, each twice as wide (wrong positions)
+        if ((c / P::NT) % 2 == 0) {
+            typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+            const u2 d = {__float_as_uint(p), __float_as_uint(p)};
+            if (c < 2048)
+                __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, vnear[c / P::NT], 0, 0);
+            else
+                __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, vgrp[c / 1024] + 4 * (c % 1024), 0, 0);
+        }
+        return;
+#endif
         if (c < 2048)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(p), rsrc, vnear[c / P::NT], 0, 0);
         else
@@ -374,6 +386,17 @@ template <class P, int ES = 4> struct PlaneStore { // ES: bytes per stored eleme
     __device__ __forceinline__ void bound(__amdgpu_buffer_rsrc_t rsrc, int c, float p) const
     {
         static_assert(ES == 2, "16-bit elements");
+#if BND_VARIANT == 3
+        if ((c / P::NT) % 4 == 0) {
+            typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+            const u2 d = {__float_as_uint(p) + 0xFFFFu, __float_as_uint(p)};
+            if (c < 2048)
+                __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, vnear[c / P::NT], 0, 0);
+            else
+                __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, vgrp[c / 1024] + 2 * (c % 1024), 0, 0);
+        }
+        return;
+#endif
 #if BND_VARIANT == 2
         // the upper half of (bits + 0xFFFF) stored straight from there: no shift
         const __amdgpu_buffer_rsrc_t r4 = rsrc;
@@ -389,6 +412,73 @@ template <class P, int ES = 4> struct PlaneStore { // ES: bytes per stored eleme
         else
             __builtin_amdgcn_raw_buffer_store_b16(b, rsrc, vgrp[c / 1024] + 2 * (c % 1024), 0, 0);
 #endif
+    }
+};
+
+// The same for a thread that owns output pairs (n, n + 1), n = 2t + STEP*f (the paired last pass
+// of afft::fft3x): a pair of powers is one 8-byte store, a pair of bounds one 4-byte store --
+// half as many store instructions as outputs for the powers, a quarter in all with the bounds.
+// Columns are even (n - shift with both even) and a block's first column and width are even,
+// so a pair is kept or dropped as a whole and every access is aligned to its size.
+// Offsets that can be negative (n < 2048) again have a register of their own.
+template <class P> struct PairStore {
+    static constexpr int STEP = P::R1 * P::R2, NF = P::R3;
+    static constexpr int NEARF = 2048 / STEP < NF ? 2048 / STEP : NF;   // outputs below 2048: exact offsets
+    static constexpr int G4 = 4096 / (4 * STEP) > 0 ? 4096 / (4 * STEP) : 1; // f's per offset register, powers
+    static constexpr int G2 = 4096 / (2 * STEP) > 0 ? 4096 / (2 * STEP) : 1; // f's per offset register, bounds
+    static constexpr int NG4 = (NF - NEARF + G4 - 1) / G4, NG2 = (NF - NEARF + G2 - 1) / G2;
+    int near4[NEARF], grp4[NG4 > 0 ? NG4 : 1];
+    int near2[NEARF], grp2[NG2 > 0 ? NG2 : 1];
+    __device__ __forceinline__ PairStore(int t, int shift, bool bounds)
+    {
+        const int c0 = 2 * t - shift; // column of the thread's first pair
+#pragma unroll
+        for (int f = 0; f < NEARF; f++) {
+            near4[f] = 4 * (c0 + STEP * f);
+            asm("" : "+v"(near4[f])); // opaque: the sum must not be split into base + immediate again
+            near2[f] = bounds ? 2 * (c0 + STEP * f) : 0;
+            asm("" : "+v"(near2[f]));
+        }
+#pragma unroll
+        for (int g = 0; g < NG4; g++) {
+            grp4[g] = 4 * (c0 + STEP * (NEARF + G4 * g));
+            asm("" : "+v"(grp4[g]));
+        }
+#pragma unroll
+        for (int g = 0; g < NG2; g++) {
+            grp2[g] = bounds ? 2 * (c0 + STEP * (NEARF + G2 * g)) : 0;
+            asm("" : "+v"(grp2[g]));
+        }
+    }
+    __device__ __forceinline__ void refresh(bool bounds)
+    {
+#pragma unroll
+        for (int g = 0; g < NG4; g++)
+            asm volatile("" : "+v"(grp4[g]));
+        if (bounds) {
+#pragma unroll
+            for (int g = 0; g < NG2; g++)
+                asm volatile("" : "+v"(grp2[g]));
+        }
+    }
+    // f is the compile-time index of the pair (its outputs are 2t + STEP*f and the next one)
+    __device__ __forceinline__ void powers(__amdgpu_buffer_rsrc_t rsrc, int f, float p0, float p1) const
+    {
+        typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+        const u2 d = {__float_as_uint(p0), __float_as_uint(p1)};
+        if (f < NEARF)
+            __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, near4[f], 0, 0);
+        else
+            __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, grp4[(f - NEARF) / G4] + 4 * STEP * ((f - NEARF) % G4), 0, 0);
+    }
+    __device__ __forceinline__ void bounds(__amdgpu_buffer_rsrc_t rsrc, int f, float p0, float p1) const
+    {
+        // the two 16-bit upper bounds (see k_harmsum_b) side by side: the upper halves of bits + 0xFFFF
+        const unsigned int d = __builtin_amdgcn_perm(__float_as_uint(p1) + 0xFFFFu, __float_as_uint(p0) + 0xFFFFu, 0x07060302u);
+        if (f < NEARF)
+            __builtin_amdgcn_raw_buffer_store_b32(d, rsrc, near2[f], 0, 0);
+        else
+            __builtin_amdgcn_raw_buffer_store_b32(d, rsrc, grp2[(f - NEARF) / G2] + 2 * STEP * ((f - NEARF) % G2), 0, 0);
     }
 };
 
@@ -476,7 +566,8 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate(
 // ---------------------------------------------------------------------------
 // BND: every power is stored a second time, rounded up to 16 bits, into `bound`, a plane of
 // the same shape (the harmonic sum reads that one and the float plane only where it matters).
-template <class P, bool KEEPK, int SER, bool ZL = false, class Stamp = afft::NoStamp, bool BND = false>
+// PAIR (8192-point plan): the last pass hands a thread adjacent outputs, stored two at a time.
+template <class P, bool KEEPK, int SER, bool ZL = false, class Stamp = afft::NoStamp, bool BND = false, bool PAIR = false>
 __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
     const c32 *__restrict__ bank, const c32 *__restrict__ blockfft,
     const int64_t *__restrict__ blk_col, const int *__restrict__ blk_ncols, int nblk, int chunk,
@@ -546,8 +637,9 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
     }
     float *prow = plane + (size_t) z * (size_t) rlen;
     const int shift = 2 * halfwidth;
-    PlaneStore<P> put(t, shift);
-    PlaneStore<P, 2> put16(t, BND ? shift : 0);
+    PlaneStore<P> put(t, PAIR ? 0 : shift);
+    PlaneStore<P, 2> put16(t, BND && !PAIR ? shift : 0);
+    PairStore<P> put2(t, PAIR ? shift : 0, BND);
     // every twiddle of passes 1 and 2, formed once and kept in registers for the whole chunk
     c32 W1[P::R1 - 1], W2[P::R2 - 1];
     afft::expand_twiddles<P::R1>(W1, w1);
@@ -567,10 +659,13 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
         float *out = (ZL ? plane + (size_t) it * (size_t) rlen : prow) + blk_col[blk];
         const int ncols = blk_ncols[blk];
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, ncols * 4, 0x00020000);
-        put.refresh();
+        if constexpr (PAIR)
+            put2.refresh(BND);
+        else
+            put.refresh();
         unsigned short *out16 = BND ? bound + (size_t) (ZL ? it : z) * (size_t) rlen + blk_col[blk] : nullptr;
         const __amdgpu_buffer_rsrc_t rsrc16 = __builtin_amdgcn_make_buffer_rsrc(out16, 0, BND && BND_VARIANT != 1 ? ncols * 2 : 0, 0x00020000);
-        if constexpr (BND)
+        if constexpr (BND && !PAIR)
             put16.refresh();
         // launder the pointer: the loads must stay inside the loop (hoisted, they
         // would pin another 2*R1 registers across the whole transform)
@@ -592,33 +687,46 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        afft::fft3x<P, +1, SER>(
-            lds,
-            [&](int, int a, int) {
-                if constexpr (KEEPK)
-                    return afft::cmul_conj_v(dreg[a % H], kreg[a]);
-                else
-                    return afft::cmul_conj_v(dreg[a % H], kv[a]);
-            },
-            [&](int, int, c32 *v) { afft::apply_twiddles_full<P::R1>(v, W1); },
-            [&](int, int, c32 *v) { afft::apply_twiddles_full<P::R2>(v, W2); },
-            [&] {
-                // the block spectrum is used up by pass 1: fetch the next block's into the
-                // same registers now, so that it arrives during passes 2 and 3
-                if (!ZL && it + 1 < b1) {
-                    const c32 *D = blockfft + (size_t) (it + 1) * NF;
+        auto load = [&](int, int a, int) {
+            if constexpr (KEEPK)
+                return afft::cmul_conj_v(dreg[a % H], kreg[a]);
+            else
+                return afft::cmul_conj_v(dreg[a % H], kv[a]);
+        };
+        auto tw1 = [&](int, int, c32 *v) { afft::apply_twiddles_full<P::R1>(v, W1); };
+        auto tw2 = [&](int, int, c32 *v) { afft::apply_twiddles_full<P::R2>(v, W2); };
+        auto mid = [&] {
+            // the block spectrum is used up by pass 1: fetch the next block's into the
+            // same registers now, so that it arrives during passes 2 and 3
+            if (!ZL && it + 1 < b1) {
+                const c32 *D = blockfft + (size_t) (it + 1) * NF;
 #pragma unroll
-                    for (int a = 0; a < H; a++)
-                        dreg[a] = D[P::M1 * a + t];
-                }
-            },
-            [&](int n, c32 v) {
-                const float pw = v.x * v.x + v.y * v.y;
-                put(rsrc, n - t, pw);
-                if constexpr (BND)
-                    put16.bound(rsrc16, n - t, pw);
-            },
-            stamp);
+                for (int a = 0; a < H; a++)
+                    dreg[a] = D[P::M1 * a + t];
+            }
+        };
+        if constexpr (PAIR) {
+            afft::fft3x<P, +1, SER, true>(
+                lds, load, tw1, tw2, mid,
+                [&](int n, c32 v, c32 w) {
+                    const int f = (n - 2 * t) / (P::R1 * P::R2);
+                    const float p0 = v.x * v.x + v.y * v.y, p1 = w.x * w.x + w.y * w.y;
+                    put2.powers(rsrc, f, p0, p1);
+                    if constexpr (BND)
+                        put2.bounds(rsrc16, f, p0, p1);
+                },
+                stamp);
+        } else {
+            afft::fft3x<P, +1, SER>(
+                lds, load, tw1, tw2, mid,
+                [&](int n, c32 v) {
+                    const float pw = v.x * v.x + v.y * v.y;
+                    put(rsrc, n - t, pw);
+                    if constexpr (BND)
+                        put16.bound(rsrc16, n - t, pw);
+                },
+                stamp);
+        }
         __syncthreads();
         stamp(9);
     }
@@ -951,12 +1059,12 @@ __global__ __launch_bounds__(256) void k_harmsum_b(
     }
 }
 
-// The same with two columns per lane, 64 apart (a wave owns 128 consecutive columns): for
-// harmonic h/2^s the second column's source cell lies exactly 64*h/2^s cells after the
-// first's (an integer for s <= 6), so both columns share one offset register per source and
-// the second load is the first with an immediate offset.  Twice the loads in flight per wave
-// for 15 registers more: the kernel is bound by load latency at full occupancy.
-template <int NSTAGES>
+// The same with NC columns per lane, 64 apart (a wave owns 64*NC consecutive columns): for
+// harmonic h/2^s the k-th column's source cell lies exactly 64*k*h/2^s cells after the
+// first's (an integer for s <= 6), so all columns share one offset register per source and
+// their loads differ by an immediate offset.  NC times the loads in flight per wave for 15
+// registers per extra column: the kernel is bound by load latency at full occupancy.
+template <int NSTAGES, int NC>
 __global__ __launch_bounds__(256) void k_harmsum_bw(
     const float *__restrict__ plane, const unsigned short *__restrict__ bound, int64_t rlen, int numz,
     int64_t col0, int64_t ncols, const int64_t *__restrict__ rowoff, const uint32_t *__restrict__ rowchg,
@@ -964,23 +1072,27 @@ __global__ __launch_bounds__(256) void k_harmsum_bw(
     int xcd_remap)
 {
     constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
+    constexpr int TILE = 256 * NC;
     const int lane = threadIdx.x & 63;
     unsigned int tile = blockIdx.x;
     if (xcd_remap) {
         const unsigned int per = (gridDim.x + 7) / 8;
         tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
-        if ((int64_t) tile * 512 >= ncols)
+        if ((int64_t) tile * TILE >= ncols)
             return;
     }
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
-    const int64_t c0 = (int64_t) tile * 512 + 128 * wave; // the wave's first column
+    const int64_t c0 = (int64_t) tile * TILE + 64 * NC * wave; // the wave's first column
     if (c0 >= ncols)
         return; // nothing to do for the whole wave (the kernel has no barriers)
     const int64_t R0 = col0 + c0;
-    const bool live0 = c0 + lane < ncols, live1 = c0 + lane + 64 < ncols;
+    bool live[NC];
+#pragma unroll
+    for (int k = 0; k < NC; k++)
+        live[k] = c0 + lane + 64 * k < ncols;
     // dead lanes read valid cells: the wave's first column, and the plane extends a block past the last searched column
-    const int t = live0 ? lane : 0;
-    const uint32_t toff = 2u * (uint32_t) t; // the lane's byte offset in the wave's 128 bytes of a row of bounds
+    const int t = live[0] ? lane : 0;
+    const uint32_t toff = 2u * (uint32_t) t; // the lane's byte offset in the wave's first 128 bytes of a row of bounds
     uint32_t off[NHS]; // byte offset of the first column's source cell in a row of bounds
     {
         int i = 0;
@@ -992,11 +1104,13 @@ __global__ __launch_bounds__(256) void k_harmsum_bw(
     }
     const char *bbytes = reinterpret_cast<const char *>(bound);
     const char *pbytes = reinterpret_cast<const char *>(plane);
-    uint32_t v0[NHS], v1[NHS]; // the sources' bounds, 16 bits each, of the two columns
+    uint32_t v[NC][NHS]; // the sources' bounds, 16 bits each, per column
     for (int zi = 0; zi < numz; zi++) {
         const char *frow = bbytes + 2 * ((size_t) zi * (size_t) rlen + (size_t) R0); // scalar
-        const uint32_t f0 = *reinterpret_cast<const unsigned short *>(frow + toff);
-        const uint32_t f1 = *reinterpret_cast<const unsigned short *>(frow + toff + 128);
+        uint32_t f[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            f[k] = *reinterpret_cast<const unsigned short *>(frow + toff + 128 * k);
         const uint32_t chg = NH > 0 ? rowchg[zi] : 0u;
         int64_t ro[NHS]; // byte offsets of the source rows in the float plane; half of that in the bounds
 #pragma unroll
@@ -1012,31 +1126,32 @@ __global__ __launch_bounds__(256) void k_harmsum_bw(
             if (chg & (1u << i)) {
                 const int s = harm_stage_of(i), h = harm_num_of(i);
                 const char *src = bbytes + (ro[i] >> 1) + off[i];
-                v0[i] = *reinterpret_cast<const unsigned short *>(src);
-                v1[i] = *reinterpret_cast<const unsigned short *>(src + 2 * ((64 * h) >> s));
+#pragma unroll
+                for (int k = 0; k < NC; k++)
+                    v[k][i] = *reinterpret_cast<const unsigned short *>(src + 2 * ((64 * k * h) >> s));
             }
         }
-        float p0 = __uint_as_float(f0 << 16), p1 = __uint_as_float(f1 << 16);
+        // one column after the other: summed side by side the compiler packs the columns' 16-bit
+        // values into shared registers, which costs a wait for its load inside every reload branch
         bool any = false;
-        {
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+            float p = __uint_as_float(f[k] << 16);
             int i = 0;
 #pragma unroll
             for (int s = 0; s < NSTAGES; s++) {
                 if (s > 0) {
 #pragma unroll
-                    for (int h = 1; h < (1 << s); h += 2) {
-                        p0 += __uint_as_float(v0[i] << 16);
-                        p1 += __uint_as_float(v1[i] << 16);
-                        i++;
-                    }
+                    for (int h = 1; h < (1 << s); h += 2)
+                        p += __uint_as_float(v[k][i++] << 16);
                 }
-                any |= (live0 && (p0 > prm.powcut[s])) | (live1 && (p1 > prm.powcut[s]));
+                any |= live[k] && (p > prm.powcut[s]);
             }
         }
         if (__ballot(any)) { // rare: this row again, from the float plane, one column after the other
-#pragma unroll 1
-            for (int k = 0; k < 2; k++) {
-                const bool live = k ? live1 : live0;
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                const bool lv = c0 + lane + 64 * k < ncols;
                 const int64_t rind = R0 + t + 64 * k;
                 float q = plane[(size_t) zi * (size_t) rlen + rind];
                 float ps[NSTAGES];
@@ -1051,7 +1166,7 @@ __global__ __launch_bounds__(256) void k_harmsum_bw(
                             const int sI = harm_stage_of(i0 + j), hI = harm_num_of(i0 + j); // constants once unrolled
                             uint32_t o = off[i0 + j];
                             asm volatile("" : "+v"(o) : "v"(q));
-                            o = 2u * o + (k ? 4u * (uint32_t) ((64 * hI) >> sI) : 0u); // a row is < 4 GB
+                            o = 2u * o + 4u * (uint32_t) ((64 * k * hI) >> sI); // a row is < 4 GB
                             e[j] = *reinterpret_cast<const float *>(pbytes + ro[i0 + j] + o);
                         }
 #pragma unroll
@@ -1065,7 +1180,7 @@ __global__ __launch_bounds__(256) void k_harmsum_bw(
                 }
 #pragma unroll
                 for (int s = 0; s < NSTAGES; s++) {
-                    const bool hit = live && (ps[s] > prm.powcut[s]);
+                    const bool hit = lv && (ps[s] > prm.powcut[s]);
                     const unsigned long long mask = __ballot(hit);
                     if (mask) {
                         unsigned int base = 0;

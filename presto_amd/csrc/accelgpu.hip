@@ -96,6 +96,7 @@ struct Tuning {
     int corr_tz = -1;       // XCD tile: owned items per tile; -1: 4 on large grids, plain grid otherwise; 0: plain grid
     int corr_tc = 16;       // XCD tile: chunks per tile
     int corr_lds = 0;       // plane generation: extra bytes of dynamic LDS (caps the workgroups per CU; experiments)
+    int corr_pair = 1;      // plane generation, 8192 points: outputs stored in adjacent pairs (0: singly)
     int hs_xcd_remap = 1;   // harmonic sum: each XCD takes one contiguous run of columns
     int hs_lds = 0;         // harmonic sum: bytes of dynamic LDS (caps the waves per CU)
     int hs_lean_from = 6;   // harmonic sum: register-lean form from this many stages on
@@ -562,20 +563,26 @@ int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const i
     } else {
         rgrid = corr_grid(tn, ctx->numz, (int) grid.y, &tile_z, &tile_c);
     }
-#define LAUNCH_RR(PLAN, ZL, BND)                                                               \
-    hipLaunchKernelGGL((accelk::k_correlate_rr<PLAN, false, 16, ZL, afft::NoStamp, BND>), rgrid, dim3(PLAN::NT),   \
+#define LAUNCH_RR(PLAN, ZL, BND, PAIR)                                                         \
+    hipLaunchKernelGGL((accelk::k_correlate_rr<PLAN, false, 16, ZL, afft::NoStamp, BND, PAIR>), rgrid, dim3(PLAN::NT),   \
                        PLAN::LDS_BYTES + std::min(std::max(tn.corr_lds, 0), 20000), ctx->stream, ctx->d_bank, d_blockfft, d_col, d_ncols,   \
                        nblk, chunk, d_plane, rlen, ctx->halfwidth, ctx->pw_inv.pw1,            \
                        ctx->pw_inv.pw2, ctx->numz, tile_z, tile_c, afft::NoStamp(), d_bound)
-    if (rr && zl && d_bound) {
-        if (ctx->fftlen == 8192) LAUNCH_RR(P8K, true, true);
-        else LAUNCH_RR(P16K, true, true);
+    // 8192 points, loop over templates: the last pass hands a thread adjacent outputs, stored two
+    // at a time (corr_pair = 0: one at a time, for comparisons; the powers are the same bits)
+    const bool pair = tn.corr_pair != 0;
+    if (rr && zl && ctx->fftlen == 8192 && pair) {
+        if (d_bound) LAUNCH_RR(P8K, true, true, true);
+        else LAUNCH_RR(P8K, true, false, true);
+    } else if (rr && zl && d_bound) {
+        if (ctx->fftlen == 8192) LAUNCH_RR(P8K, true, true, false);
+        else LAUNCH_RR(P16K, true, true, false);
     } else if (rr && ctx->fftlen == 8192) {
-        if (zl) LAUNCH_RR(P8K, true, false);
-        else LAUNCH_RR(P8K, false, false);
+        if (zl) LAUNCH_RR(P8K, true, false, false);
+        else LAUNCH_RR(P8K, false, false, false);
     } else if (rr) {
-        if (zl) LAUNCH_RR(P16K, true, false);
-        else LAUNCH_RR(P16K, false, false);
+        if (zl) LAUNCH_RR(P16K, true, false, false);
+        else LAUNCH_RR(P16K, false, false, false);
 #undef LAUNCH_RR
     } else if (ctx->fftlen == 8192) {
         hipLaunchKernelGGL((accelk::k_correlate<P8K, false>), grid, dim3(P8K::NT), P8K::LDS_BYTES,
@@ -701,25 +708,28 @@ int launch_harmsum(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, 
     hipLaunchKernelGGL((accelk::k_harmsum_b<NS>), dim3(ntiles), dim3(256), ctx->tune.hs_lds, ctx->stream, \
                        ctx->d_plane, ctx->d_bound, ctx->setup.rlen, ctx->numz, col0, ncols, ctx->d_rowoff, \
                        ctx->d_rowchg, prm, out.hits, out.count, cap, remap)
-#define LAUNCH_HSBW(NS)                                                                                    \
-    hipLaunchKernelGGL((accelk::k_harmsum_bw<NS>), dim3(ntiles2), dim3(256), ctx->tune.hs_lds, ctx->stream, \
-                       ctx->d_plane, ctx->d_bound, ctx->setup.rlen, ctx->numz, col0, ncols, ctx->d_rowoff, \
-                       ctx->d_rowchg, prm, out.hits, out.count, cap, remap)
-            unsigned ntiles2 = (unsigned) ((ncols + 511) / 512);
-            if (remap)
-                ntiles2 = ((ntiles2 + 7) / 8) * 8;
-            // Two columns per lane (twice the loads in flight) once there are enough columns to fill the
-            // device with half as many workgroups: 2^23 points, zmax 200, 16 harmonics 3.49 against 4.2 ms,
-            // 8 harmonics 2.03 against 2.95 ms; 2^21 points, zmax 50 0.315 against 0.245 ms.
-            // hs_bound = 2 / 3 force the one-column / the two-column kernel.
+#define LAUNCH_HSBW(NS, NC)                                                                                \
+    do {                                                                                                   \
+        unsigned nt = (unsigned) ((ncols + 256 * NC - 1) / (256 * NC));                                    \
+        if (remap)                                                                                         \
+            nt = ((nt + 7) / 8) * 8;                                                                       \
+        hipLaunchKernelGGL((accelk::k_harmsum_bw<NS, NC>), dim3(nt), dim3(256), ctx->tune.hs_lds, ctx->stream, \
+                           ctx->d_plane, ctx->d_bound, ctx->setup.rlen, ctx->numz, col0, ncols, ctx->d_rowoff, \
+                           ctx->d_rowchg, prm, out.hits, out.count, cap, remap);                           \
+    } while (0)
+            // Several columns per lane (as many times the loads in flight) once there are enough columns
+            // to fill the device with that many fewer workgroups; as many columns as keep eight waves
+            // per SIMD (64 registers).  2^23 points, zmax 200: 16 harmonics 3.49 (two columns) against
+            // 4.2 ms (one), 8 harmonics 2.03 against 2.95 ms; 2^21 points, zmax 50: 0.315 against 0.245 ms.
+            // hs_bound = 2 / 3 force the one-column / the wide kernel.
             const bool wide = ctx->tune.hs_bound == 3 ||
                               (ctx->tune.hs_bound == 1 && nstages >= 4 && ncols >= ((int64_t) 1 << 22));
             switch (nstages) {
-            case 1: if (wide) LAUNCH_HSBW(1); else LAUNCH_HSB(1); break;
-            case 2: if (wide) LAUNCH_HSBW(2); else LAUNCH_HSB(2); break;
-            case 3: if (wide) LAUNCH_HSBW(3); else LAUNCH_HSB(3); break;
-            case 4: if (wide) LAUNCH_HSBW(4); else LAUNCH_HSB(4); break;
-            default: if (wide) LAUNCH_HSBW(5); else LAUNCH_HSB(5); break;
+            case 1: if (wide) LAUNCH_HSBW(1, 4); else LAUNCH_HSB(1); break;
+            case 2: if (wide) LAUNCH_HSBW(2, 4); else LAUNCH_HSB(2); break;
+            case 3: if (wide) LAUNCH_HSBW(3, 4); else LAUNCH_HSB(3); break;
+            case 4: if (wide) LAUNCH_HSBW(4, 3); else LAUNCH_HSB(4); break;
+            default: if (wide) LAUNCH_HSBW(5, 2); else LAUNCH_HSB(5); break;
             }
 #undef LAUNCH_HSB
 #undef LAUNCH_HSBW
@@ -1053,6 +1063,7 @@ const TuneName kTuneNames[] = {
     {"corr_rr", &Tuning::corr_rr},           {"corr_zl", &Tuning::corr_zl},
     {"corr_chunk", &Tuning::corr_chunk},     {"corr_tz", &Tuning::corr_tz},
     {"corr_tc", &Tuning::corr_tc},           {"corr_lds", &Tuning::corr_lds},
+    {"corr_pair", &Tuning::corr_pair},
             {"hs_xcd_remap", &Tuning::hs_xcd_remap},
     {"hs_lds", &Tuning::hs_lds},             {"hs_lean_from", &Tuning::hs_lean_from},
     {"hs_j", &Tuning::hs_j},                 {"hs_chunk_blocks", &Tuning::hs_chunk_blocks},
@@ -1191,6 +1202,8 @@ int accelgpu_create(accelgpu_ctx **out, int device)
     if ((rc = allow_lds(accelk::k_correlate_rr<P16K, false, 16, false>, P16K::LDS_BYTES + 20000))) return rc;
     if ((rc = allow_lds(accelk::k_correlate_rr<P16K, false, 16, true>, P16K::LDS_BYTES + 20000))) return rc;
     if ((rc = allow_lds(accelk::k_correlate_rr<P8K, false, 16, true, afft::NoStamp, true>, P8K::LDS_BYTES + 20000))) return rc;
+    if ((rc = allow_lds(accelk::k_correlate_rr<P8K, false, 16, true, afft::NoStamp, true, true>, P8K::LDS_BYTES + 20000))) return rc;
+    if ((rc = allow_lds(accelk::k_correlate_rr<P8K, false, 16, true, afft::NoStamp, false, true>, P8K::LDS_BYTES + 20000))) return rc;
     if ((rc = allow_lds(accelk::k_correlate_rr<P16K, false, 16, true, afft::NoStamp, true>, P16K::LDS_BYTES + 20000))) return rc;
     if ((rc = allow_lds(accelk::k_fft_rows<P8K, -1>, P8K::LDS_BYTES))) return rc;
     if ((rc = allow_lds(accelk::k_fft_rows<P16K, -1>, P16K::LDS_BYTES))) return rc;

@@ -305,8 +305,11 @@ struct NoStamp {
     __device__ __forceinline__ void operator()(int) const {}
 };
 
-template <class P, int DIR, int SER = 0, class Load, class Tw1, class Tw2, class Mid, class Store,
-          class Stamp = NoStamp>
+// PAIR (plans with two pass-3 butterflies per thread): the thread takes butterflies 2t and 2t + 1
+// instead of t and t + NT, so that it owns outputs n and n + 1 for n = 2t + R1*R2*f, and
+// store(n, v, w) receives both: the caller can store them as one wider access.
+template <class P, int DIR, int SER = 0, bool PAIR = false, class Load, class Tw1, class Tw2, class Mid,
+          class Store, class Stamp = NoStamp>
 __device__ __forceinline__ void fft3x(c32 *lds, Load load, Tw1 tw1, Tw2 tw2, Mid mid, Store store,
                                       Stamp stamp = Stamp())
 {
@@ -348,25 +351,46 @@ __device__ __forceinline__ void fft3x(c32 *lds, Load load, Tw1 tw1, Tw2 tw2, Mid
         const int d = g % P::R3, n1 = g / P::R3;
         Dft<P::R2, DIR, SER>::run(&v[u * P::R2]);
         tw2(u, d, &v[u * P::R2]);
+        // PAIR: one more element of padding per e, so that the paired pass-3 reads (lanes 0-15 and
+        // 16-31 of a group read rows e and e + 1 at every other n1) fall on disjoint banks
 #pragma unroll
         for (int e = 0; e < P::R2; e++)
-            lds[(e * P::R3 + d) * P::S2 + n1] = v[u * P::R2 + e];
+            lds[(e * P::R3 + d) * P::S2 + n1 + (PAIR ? e : 0)] = v[u * P::R2 + e];
     }
     stamp(6); // pass-2 arithmetic done, second image written (issued)
     __syncthreads();
     stamp(7);
 
+    if constexpr (PAIR) {
+        static_assert(P::B3 == 2, "pairs need two pass-3 butterflies per thread");
 #pragma unroll
-    for (int u = 0; u < P::B3; u++) {
-        const int g = t + P::NT * u;
-        const int n1 = g % P::R1, e = g / P::R1;
+        for (int u = 0; u < 2; u++) {
+            const int g = 2 * t + u;
+            const int n1 = g % P::R1, e = g / P::R1;
 #pragma unroll
-        for (int d = 0; d < P::R3; d++)
-            v[u * P::R3 + d] = lds_read(&lds[(e * P::R3 + d) * P::S2 + n1]);
-        Dft<P::R3, DIR, SER>::run(&v[u * P::R3]);
+            for (int d = 0; d < P::R3; d++)
+                v[u * P::R3 + d] = lds_read(&lds[(e * P::R3 + d) * P::S2 + n1 + e]);
+        }
+        static_assert((P::R2 * P::R3 * P::S2 + P::R2) * sizeof(c32) <= P::LDS_BYTES, "padded second image fits");
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            Dft<P::R3, DIR, SER>::run(&v[u * P::R3]);
 #pragma unroll
         for (int f = 0; f < P::R3; f++)
-            store(g + P::R1 * P::R2 * f, v[u * P::R3 + f]);
+            store(2 * t + P::R1 * P::R2 * f, v[f], v[P::R3 + f]);
+    } else {
+#pragma unroll
+        for (int u = 0; u < P::B3; u++) {
+            const int g = t + P::NT * u;
+            const int n1 = g % P::R1, e = g / P::R1;
+#pragma unroll
+            for (int d = 0; d < P::R3; d++)
+                v[u * P::R3 + d] = lds_read(&lds[(e * P::R3 + d) * P::S2 + n1]);
+            Dft<P::R3, DIR, SER>::run(&v[u * P::R3]);
+#pragma unroll
+            for (int f = 0; f < P::R3; f++)
+                store(g + P::R1 * P::R2 * f, v[u * P::R3 + f]);
+        }
     }
     stamp(8); // pass-3 arithmetic done, outputs stored (issued)
 }

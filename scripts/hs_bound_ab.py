@@ -11,7 +11,7 @@ from presto_amd import synth                 # noqa: E402
 
 SUMF2 = {1: 0.0, 2: 0.25, 4: 0.875, 8: 2.1875, 16: 4.84375, 32: 10.171875}
 CASES = {"cfg1": (1 << 19, 1e-4, 0, 8), "cfg2": (1 << 22, 64e-6, 200, 16), "cfg2h8": (1 << 22, 64e-6, 200, 8),
-         "cfg2h4": (1 << 22, 64e-6, 200, 4), "cfg2s": (1 << 20, 64e-6, 50, 16),
+         "cfg2h4": (1 << 22, 64e-6, 200, 4), "cfg2h2": (1 << 22, 64e-6, 200, 2), "cfg2h1": (1 << 22, 64e-6, 200, 1), "cfg2s": (1 << 20, 64e-6, 50, 16),
          "cfg4": (1 << 26, 64e-6, 300, 16)}
 g = pa.AccelSearchGPU(0)
 for name in sys.argv[1:] or ["cfg2s", "cfg2"]:
@@ -25,7 +25,7 @@ for name in sys.argv[1:] or ["cfg2s", "cfg2"]:
     g.load_fft(fft)
     g.set_profiling(True)
     res = {}
-    for mode in (0, 1, 3, 1, 3):
+    for mode in (0, 1, 2, 3):
         g.set_tuning("hs_bound", mode)
         hits = g.run(max_hits=1 << 22)
         g.timings()
