@@ -239,7 +239,13 @@ def main():
 
     if rank == 0:
         cells = setup.numz * 7470 * setup.num_search_blocks
-        alg_bytes = 4.0 * (1.0 + SUMF2[cfg["numharm"]]) * cells
+        # Bytes the harmonic sum has to move: one value per (cell, source), sources = the fundamental
+        # and the sub-harmonics' Σ f^2 distinct cells per fundamental cell.  The kernel reads the
+        # 16-bit upper bounds of the plane (2 B per value) and the float plane only for the rows
+        # where a bound crosses a threshold; without the bounds it reads floats (4 B per value).
+        bounded = g.get_tuning("hs_bound_active") == 1
+        float_bytes = 4.0 * (1.0 + SUMF2[cfg["numharm"]]) * cells
+        alg_bytes = float_bytes / 2 if bounded else float_bytes
         hs = tm["harmsum"]
         hs_ms = hs["total_ms"] / max(hs["launches"], 1)
         achieved = alg_bytes / (hs_ms * 1e-3) / 1e9 if hs_ms > 0 else 0.0
@@ -248,8 +254,10 @@ def main():
         if os.path.exists(pmc_path) and args.log2n == 23:
             # PMC counters cannot be read inside a timed run: this is the committed
             # rocprofv3 measurement of the same kernel on the same workload
-            traffic = json.load(open(pmc_path))["hbm_bytes_per_launch"]
-            traffic_source = "profiles/pmc_harmsum.json (rocprofv3 --pmc passes of this command, not this run)"
+            pmc = json.load(open(pmc_path))
+            if pmc.get("bounded", False) == bounded:
+                traffic = pmc["hbm_bytes_per_launch"]
+                traffic_source = "profiles/pmc_harmsum.json (rocprofv3 --pmc passes of this command, not this run)"
         line = {
             "metric": "DM-trial .fft searches/sec (2^%d pts, zmax=%d, numharm=%d)"
                       % (args.log2n, cfg["zmax"], cfg["numharm"]),
@@ -264,11 +272,17 @@ def main():
                        "numbins": numbins, "numz": setup.numz, "fftlen": setup.fftlen,
                        "search_blocks": setup.num_search_blocks, "plane_GB": setup.plane_bytes / 1e9,
                        "trials_per_gpu": args.steps, "parallelism": "dm-trials x%d" % world},
-            "roofline": {"kernel": "k_harmsum<%d stages>" % setup.numharmstages, "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": ("k_harmsum_bw<%d stages> over 16-bit upper bounds of the plane" if bounded
+                                    else "k_harmsum<%d stages>") % setup.numharmstages,
+                         "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": hs_ms},
+                         "avg_launch_ms": hs_ms,
+                         # the same launch priced as if it had read the float plane (the kernel of the
+                         # earlier rounds, 4 B per value): comparable with their `achieved`
+                         "float_plane_bytes_per_launch": float_bytes,
+                         "float_plane_equivalent_GBps": float_bytes / (hs_ms * 1e-3) / 1e9 if hs_ms > 0 else 0.0},
             "kernels_ms_per_step": {k: v["total_ms"] / max(args.steps, 1) for k, v in tm.items()},
             "hits_per_trial": float(np.mean([r[0] for r in results])),
             "cands_per_trial": float(np.mean([len(r[1]) for r in results])),

@@ -106,6 +106,14 @@ int accelgpu_synchronize(accelgpu_ctx *ctx);
  *   use_graph      1   searches with a plane of at most 64 MB: the whole launch is captured once
  *                      per (hit buffer, spectrum buffer) as a HIP graph and replayed with one call
  *   corr_lds       0   plane generation: extra bytes of dynamic LDS per workgroup (experiments)
+ *   corr_pair      1   plane generation, 8192-point transforms: adjacent outputs stored in pairs
+ *   hs_bound       1   harmonic sum of up to 16 harmonics over a second plane of 16-bit upper bounds
+ *                      of the powers (half the plane's size again, written by plane generation),
+ *                      exact from the float plane wherever a bound sum crosses a threshold: the
+ *                      same hits from half the bytes.  0: float plane only; 2 / 3: one / several
+ *                      columns per lane forced.  Takes effect at the next accelgpu_set_search()
+ *                      or at once if a search is set up; silently off when the memory is not there
+ *                      ("hs_bound_active", read-only: 1 if the current search uses the bounds)
  *   hits_cap   2^20    records in each device hit buffer (set: reallocates both; they
  *                      grow on their own when a search overflows them)
  * ref: none (the reference's only run-time knob is -ncpus). */

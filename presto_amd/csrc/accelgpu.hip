@@ -1313,6 +1313,10 @@ int accelgpu_get_tuning(accelgpu_ctx *ctx, const char *name, int *value)
         *value = (int) std::min<size_t>(std::min(ctx->slots[0].cap, ctx->slots[1].cap), 0x7FFFFFFF);
         return ACCELGPU_OK;
     }
+    if (!strcmp(name, "hs_bound_active")) { // read-only: does the current search sum over the 16-bit bounds?
+        *value = ctx->have_search && bounds_in_use(ctx) ? 1 : 0;
+        return ACCELGPU_OK;
+    }
     for (const TuneName &k : kTuneNames)
         if (!strcmp(name, k.name)) {
             *value = ctx->tune.*(k.field);

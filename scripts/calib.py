@@ -1,7 +1,7 @@
 """FETCH_SIZE calibration: harmonic-sum kernel with 1, 2 and 16 harmonics on a
 cfg2-sized plane.  numharm=1 streams the plane exactly once (6.74 GB)."""
-import sys, numpy as np
-sys.path.insert(0, '.')
+import os, sys, numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import presto_amd as pa
 from presto_amd import synth
 numbins = 1 << 22

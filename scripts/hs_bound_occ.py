@@ -12,7 +12,7 @@ fft = synth.make_fft(2 * numbins, dt, dict(synth.CONFIGS["cfg2"])["pulsars"], se
 setup = g.configure(numbins, 2 * numbins, dt, zmax, nh, fhi=1e9)
 g.load_fft(fft)
 g.set_profiling(True)
-g.set_tuning("hs_bound", 1)
+g.set_tuning("hs_bound", int(sys.argv[1]) if len(sys.argv) > 1 else 2)   # 2: one column per lane, 3: several
 for wgs in (8, 7, 6, 5, 4, 3):
     g.set_tuning("hs_lds", 0 if wgs == 8 else (160 * 1024) // wgs - 512)
     g.run(max_hits=1 << 22)
