@@ -107,7 +107,7 @@ int accelgpu_synchronize(accelgpu_ctx *ctx);
  *                      per (hit buffer, spectrum buffer) as a HIP graph and replayed with one call
  *   corr_lds       0   plane generation: extra bytes of dynamic LDS per workgroup (experiments)
  *   corr_pair      1   plane generation, 8192-point transforms: adjacent outputs stored in pairs
- *   hs_bound       1   harmonic sum of up to 16 harmonics over a second plane of 16-bit upper bounds
+ *   hs_bound       1   harmonic sum over a second plane of 16-bit upper bounds
  *                      of the powers (half the plane's size again, written by plane generation),
  *                      exact from the float plane wherever a bound sum crosses a threshold: the
  *                      same hits from half the bytes.  0: float plane only; 2 / 3: one / several

@@ -600,7 +600,7 @@ int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const i
 // Does the harmonic sum of this search read the 16-bit bounds (k_harmsum_b)?
 bool bounds_in_use(const accelgpu_ctx *ctx)
 {
-    return ctx->tune.hs_bound && ctx->d_bound && ctx->inmem && ctx->setup.numharmstages <= 5;
+    return ctx->tune.hs_bound && ctx->d_bound && ctx->inmem && ctx->setup.numharmstages <= 6;
 }
 
 // Where a harmonic-sum launch compacts its threshold crossings.
@@ -729,7 +729,8 @@ int launch_harmsum(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, 
             case 2: if (wide) LAUNCH_HSBW(2, 4); else LAUNCH_HSB(2); break;
             case 3: if (wide) LAUNCH_HSBW(3, 4); else LAUNCH_HSB(3); break;
             case 4: if (wide) LAUNCH_HSBW(4, 3); else LAUNCH_HSB(4); break;
-            default: if (wide) LAUNCH_HSBW(5, 2); else LAUNCH_HSB(5); break;
+            case 5: if (wide) LAUNCH_HSBW(5, 2); else LAUNCH_HSB(5); break;
+            default: LAUNCH_HSB(6); break; // 31 sub-harmonics: 92 registers with one column per lane
             }
 #undef LAUNCH_HSB
 #undef LAUNCH_HSBW
@@ -1542,7 +1543,7 @@ namespace {
 int reserve_bounds(accelgpu_ctx *ctx)
 {
     const size_t plane_elems = (size_t) ctx->setup.rlen * ctx->numz;
-    if (!ctx->tune.hs_bound || !ctx->d_plane || plane_elems == 0 || ctx->setup.numharmstages > 5)
+    if (!ctx->tune.hs_bound || !ctx->d_plane || plane_elems == 0 || ctx->setup.numharmstages > 6)
         return ACCELGPU_OK;
     if (ctx->bound_cap >= plane_elems && ctx->d_bound)
         return ACCELGPU_OK;

@@ -44,7 +44,7 @@ def _assert_same(res):
         assert len(h) == len(ref) and h.tobytes() == ref.tobytes(), "hs_bound=%d differs from the float-plane sum" % m
 
 
-@pytest.mark.parametrize("numharm", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("numharm", [1, 2, 4, 8, 16, 32])
 @pytest.mark.parametrize("zmax", [0, 20, 200])
 def test_same_hits_for_every_number_of_harmonics(gpu, numharm, zmax):
     N, dt = 1 << 20, 1e-4
