@@ -333,9 +333,6 @@ __global__ __launch_bounds__(P::NT) void k_block_prep(
 // reaches the range check as a large unsigned number; the others share one register per
 // 4096 bytes (never negative) and carry the rest as the instruction's immediate.
 // ---------------------------------------------------------------------------
-#ifndef BND_VARIANT
-#define BND_VARIANT 0
-#endif
 template <class P, int ES = 4> struct PlaneStore { // ES: bytes per stored element
     static constexpr int NEAR = (P::N < 2048 ? P::N : 2048) / P::NT, NG = P::N >= 1024 ? P::N / 1024 : 1;
     int vnear[NEAR], vgrp[NG];
@@ -365,18 +362,6 @@ template <class P, int ES = 4> struct PlaneStore { // ES: bytes per stored eleme
     __device__ __forceinline__ void operator()(__amdgpu_buffer_rsrc_t rsrc, int c, float p) const
     {
         static_assert(ES == 4, "float elements");
-#if BND_VARIANT == 3
-        // timing only: half as many store instructions, each twice as wide (wrong positions)
-        if ((c / P::NT) % 2 == 0) {
-            typedef unsigned int u2 __attribute__((ext_vector_type(2)));
-            const u2 d = {__float_as_uint(p), __float_as_uint(p)};
-            if (c < 2048)
-                __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, vnear[c / P::NT], 0, 0);
-            else
-                __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, vgrp[c / 1024] + 4 * (c % 1024), 0, 0);
-        }
-        return;
-#endif
         if (c < 2048)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(p), rsrc, vnear[c / P::NT], 0, 0);
         else
@@ -386,32 +371,11 @@ template <class P, int ES = 4> struct PlaneStore { // ES: bytes per stored eleme
     __device__ __forceinline__ void bound(__amdgpu_buffer_rsrc_t rsrc, int c, float p) const
     {
         static_assert(ES == 2, "16-bit elements");
-#if BND_VARIANT == 3
-        if ((c / P::NT) % 4 == 0) {
-            typedef unsigned int u2 __attribute__((ext_vector_type(2)));
-            const u2 d = {__float_as_uint(p) + 0xFFFFu, __float_as_uint(p)};
-            if (c < 2048)
-                __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, vnear[c / P::NT], 0, 0);
-            else
-                __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, vgrp[c / 1024] + 2 * (c % 1024), 0, 0);
-        }
-        return;
-#endif
-#if BND_VARIANT == 2
-        // the upper half of (bits + 0xFFFF) stored straight from there: no shift
-        const __amdgpu_buffer_rsrc_t r4 = rsrc;
-        const unsigned int b = __float_as_uint(p) + 0xFFFFu;
-        if (c < 2048)
-            asm volatile("buffer_store_short_d16_hi %0, %1, %2, 0 offen" ::"v"(b), "v"(vnear[c / P::NT]), "s"(r4) : "memory");
-        else
-            asm volatile("buffer_store_short_d16_hi %0, %1, %2, 0 offen offset:%3" ::"v"(b), "v"(vgrp[c / 1024]), "s"(r4), "n"(2 * (c % 1024)) : "memory");
-#else
         const unsigned short b = (unsigned short) ((__float_as_uint(p) + 0xFFFFu) >> 16);
         if (c < 2048)
             __builtin_amdgcn_raw_buffer_store_b16(b, rsrc, vnear[c / P::NT], 0, 0);
         else
             __builtin_amdgcn_raw_buffer_store_b16(b, rsrc, vgrp[c / 1024] + 2 * (c % 1024), 0, 0);
-#endif
     }
 };
 
@@ -664,7 +628,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
         else
             put.refresh();
         unsigned short *out16 = BND ? bound + (size_t) (ZL ? it : z) * (size_t) rlen + blk_col[blk] : nullptr;
-        const __amdgpu_buffer_rsrc_t rsrc16 = __builtin_amdgcn_make_buffer_rsrc(out16, 0, BND && BND_VARIANT != 1 ? ncols * 2 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc16 = __builtin_amdgcn_make_buffer_rsrc(out16, 0, BND ? ncols * 2 : 0, 0x00020000);
         if constexpr (BND && !PAIR)
             put16.refresh();
         // launder the pointer: the loads must stay inside the loop (hoisted, they
