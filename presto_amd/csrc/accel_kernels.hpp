@@ -889,7 +889,13 @@ constexpr int harm_num_of(int i) // -> its odd numerator h
     return 2 * (i + 1 - (1 << (s - 1))) + 1;
 }
 __device__ __forceinline__ float bound_value(unsigned short b) { return __uint_as_float((uint32_t) b << 16); }
-__device__ __forceinline__ unsigned short bound_of(float p) { return (unsigned short) ((__float_as_uint(p) + 0xFFFFu) >> 16); }
+// Smallest bfloat16 >= p for any float: positive values round their magnitude up, negative ones
+// (which plane generation never produces, a host writing the plane may) truncate it.
+__device__ __forceinline__ unsigned short bound_of(float p)
+{
+    const uint32_t b = __float_as_uint(p);
+    return (unsigned short) ((b + ((int32_t) b >= 0 ? 0xFFFFu : 0u)) >> 16);
+}
 
 // bound[i] = bound_of(plane[i]): for planes written by something other than the plane
 // generation kernel (which stores both).

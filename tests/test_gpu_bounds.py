@@ -96,6 +96,9 @@ def test_plane_written_by_the_host_renews_the_bounds(gpu):
     plant = {(3, col0 + 7470 * 2 + 11): np.float32(1024.0),
              (10, col0 + 7470 * 5 + 4001): np.float32(3.3e38),
              (17, col0 + 7470 * 9 + 64): np.nextafter(np.float32(2048.0), np.float32(0.0))}
+    # values plane generation never writes but a host may: negative (its bound must round towards
+    # zero, not away from it) and NaN; neither is a hit, and neither may hide one
+    gpu.put_plane(5, col0 + 7470 * 3 + 100, np.array([-1.0000001, np.nan, -3.5e-5], dtype=np.float32))
     for (zi, col), val in plant.items():
         gpu.put_plane(zi, col, np.array([val], dtype=np.float32))
     res = _hits_by_mode(gpu, call=gpu.search_plane)
