@@ -164,3 +164,17 @@ def test_table_form_fill_leaves_no_stale_bounds(gpu):
         assert got.tobytes() == gpu.run().tobytes()
     finally:
         gpu.set_tuning("corr_rr", 1)
+
+
+def test_knob_reports_whether_the_bounds_are_in_use(gpu):
+    N, dt = 1 << 19, 1e-4
+    gpu.set_tuning("hs_bound", 1)
+    gpu.configure(N // 2, N, dt, 10, 8, fhi=1000.0)
+    assert gpu.get_tuning("hs_bound_active") == 1
+    gpu.set_tuning("hs_bound", 0)
+    assert gpu.get_tuning("hs_bound_active") == 0
+    gpu.configure(N // 2, N, dt, 10, 8, fhi=1000.0, inmem=False)      # standard mode: no plane, no bounds
+    gpu.set_tuning("hs_bound", 1)
+    assert gpu.get_tuning("hs_bound_active") == 0
+    gpu.configure(N // 2, N, dt, 10, 8, fhi=1000.0)
+    assert gpu.get_tuning("hs_bound_active") == 1
