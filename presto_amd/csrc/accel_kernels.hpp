@@ -367,21 +367,24 @@ template <class P, int ES = 4> struct PlaneStore { // ES: bytes per stored eleme
         else
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(p), rsrc, vgrp[c / 1024] + 4 * (c % 1024), 0, 0);
     }
-    // the 16-bit upper bound of p (see k_harmsum_b)
-    __device__ __forceinline__ void bound(__amdgpu_buffer_rsrc_t rsrc, int c, float p) const
+    // the power as two 16-bit halves, into the planes of upper and of lower halves (see k_harmsum_b)
+    __device__ __forceinline__ void split(__amdgpu_buffer_rsrc_t hi, __amdgpu_buffer_rsrc_t lo, int c, float p) const
     {
         static_assert(ES == 2, "16-bit elements");
-        const unsigned short b = (unsigned short) ((__float_as_uint(p) + 0xFFFFu) >> 16);
-        if (c < 2048)
-            __builtin_amdgcn_raw_buffer_store_b16(b, rsrc, vnear[c / P::NT], 0, 0);
-        else
-            __builtin_amdgcn_raw_buffer_store_b16(b, rsrc, vgrp[c / 1024] + 2 * (c % 1024), 0, 0);
+        const unsigned int b = __float_as_uint(p);
+        if (c < 2048) {
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short) (b >> 16), hi, vnear[c / P::NT], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short) b, lo, vnear[c / P::NT], 0, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short) (b >> 16), hi, vgrp[c / 1024] + 2 * (c % 1024), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short) b, lo, vgrp[c / 1024] + 2 * (c % 1024), 0, 0);
+        }
     }
 };
 
 // The same for a thread that owns output pairs (n, n + 1), n = 2t + STEP*f (the paired last pass
-// of afft::fft3x): a pair of powers is one 8-byte store, a pair of bounds one 4-byte store --
-// half as many store instructions as outputs for the powers, a quarter in all with the bounds.
+// of afft::fft3x): a pair of powers is one 8-byte store into the float plane, or -- split planes --
+// one 4-byte store of the two upper halves and one of the two lower halves.
 // Columns are even (n - shift with both even) and a block's first column and width are even,
 // so a pair is kept or dropped as a whole and every access is aligned to its size.
 // Offsets that can be negative (n < 2048) again have a register of their own.
@@ -389,18 +392,18 @@ template <class P> struct PairStore {
     static constexpr int STEP = P::R1 * P::R2, NF = P::R3;
     static constexpr int NEARF = 2048 / STEP < NF ? 2048 / STEP : NF;   // outputs below 2048: exact offsets
     static constexpr int G4 = 4096 / (4 * STEP) > 0 ? 4096 / (4 * STEP) : 1; // f's per offset register, powers
-    static constexpr int G2 = 4096 / (2 * STEP) > 0 ? 4096 / (2 * STEP) : 1; // f's per offset register, bounds
+    static constexpr int G2 = 4096 / (2 * STEP) > 0 ? 4096 / (2 * STEP) : 1; // f's per offset register, 16-bit planes
     static constexpr int NG4 = (NF - NEARF + G4 - 1) / G4, NG2 = (NF - NEARF + G2 - 1) / G2;
     int near4[NEARF], grp4[NG4 > 0 ? NG4 : 1];
     int near2[NEARF], grp2[NG2 > 0 ? NG2 : 1];
-    __device__ __forceinline__ PairStore(int t, int shift, bool bounds)
+    __device__ __forceinline__ PairStore(int t, int shift, bool halves)
     {
         const int c0 = 2 * t - shift; // column of the thread's first pair
 #pragma unroll
         for (int f = 0; f < NEARF; f++) {
             near4[f] = 4 * (c0 + STEP * f);
             asm("" : "+v"(near4[f])); // opaque: the sum must not be split into base + immediate again
-            near2[f] = bounds ? 2 * (c0 + STEP * f) : 0;
+            near2[f] = halves ? 2 * (c0 + STEP * f) : 0;
             asm("" : "+v"(near2[f]));
         }
 #pragma unroll
@@ -410,19 +413,20 @@ template <class P> struct PairStore {
         }
 #pragma unroll
         for (int g = 0; g < NG2; g++) {
-            grp2[g] = bounds ? 2 * (c0 + STEP * (NEARF + G2 * g)) : 0;
+            grp2[g] = halves ? 2 * (c0 + STEP * (NEARF + G2 * g)) : 0;
             asm("" : "+v"(grp2[g]));
         }
     }
-    __device__ __forceinline__ void refresh(bool bounds)
+    __device__ __forceinline__ void refresh(bool halves)
     {
-#pragma unroll
-        for (int g = 0; g < NG4; g++)
-            asm volatile("" : "+v"(grp4[g]));
-        if (bounds) {
+        if (halves) {
 #pragma unroll
             for (int g = 0; g < NG2; g++)
                 asm volatile("" : "+v"(grp2[g]));
+        } else {
+#pragma unroll
+            for (int g = 0; g < NG4; g++)
+                asm volatile("" : "+v"(grp4[g]));
         }
     }
     // f is the compile-time index of the pair (its outputs are 2t + STEP*f and the next one)
@@ -435,14 +439,18 @@ template <class P> struct PairStore {
         else
             __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, grp4[(f - NEARF) / G4] + 4 * STEP * ((f - NEARF) % G4), 0, 0);
     }
-    __device__ __forceinline__ void bounds(__amdgpu_buffer_rsrc_t rsrc, int f, float p0, float p1) const
+    __device__ __forceinline__ void split(__amdgpu_buffer_rsrc_t hi, __amdgpu_buffer_rsrc_t lo, int f, float p0, float p1) const
     {
-        // the two 16-bit upper bounds (see k_harmsum_b) side by side: the upper halves of bits + 0xFFFF
-        const unsigned int d = __builtin_amdgcn_perm(__float_as_uint(p1) + 0xFFFFu, __float_as_uint(p0) + 0xFFFFu, 0x07060302u);
-        if (f < NEARF)
-            __builtin_amdgcn_raw_buffer_store_b32(d, rsrc, near2[f], 0, 0);
-        else
-            __builtin_amdgcn_raw_buffer_store_b32(d, rsrc, grp2[(f - NEARF) / G2] + 2 * STEP * ((f - NEARF) % G2), 0, 0);
+        // the two upper halves side by side, and the two lower halves
+        const unsigned int h = __builtin_amdgcn_perm(__float_as_uint(p1), __float_as_uint(p0), 0x07060302u);
+        const unsigned int l = __builtin_amdgcn_perm(__float_as_uint(p1), __float_as_uint(p0), 0x05040100u);
+        if (f < NEARF) {
+            __builtin_amdgcn_raw_buffer_store_b32(h, hi, near2[f], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(l, lo, near2[f], 0, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b32(h, hi, grp2[(f - NEARF) / G2] + 2 * STEP * ((f - NEARF) % G2), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(l, lo, grp2[(f - NEARF) / G2] + 2 * STEP * ((f - NEARF) % G2), 0, 0);
+        }
     }
 };
 
@@ -528,16 +536,17 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate(
 //                      then three rows exp(+2*pi*i*b*lo/N), lo = 1..3
 //   pw2: [R2/4+2][R3]  the same for exp(+2*pi*i*d*e/M1)
 // ---------------------------------------------------------------------------
-// BND: every power is stored a second time, rounded up to 16 bits, into `bound`, a plane of
-// the same shape (the harmonic sum reads that one and the float plane only where it matters).
+// SPLIT: the plane is two planes of 16-bit values, the upper and the lower halves of every float
+// (`hi`, `lo`, each of the plane's shape; `plane` is not used): the harmonic sum reads the upper
+// halves alone -- half the bytes -- and both only where it matters (see k_harmsum_b).
 // PAIR (8192-point plan): the last pass hands a thread adjacent outputs, stored two at a time.
-template <class P, bool KEEPK, int SER, bool ZL = false, class Stamp = afft::NoStamp, bool BND = false, bool PAIR = false>
+template <class P, bool KEEPK, int SER, bool ZL = false, class Stamp = afft::NoStamp, bool SPLIT = false, bool PAIR = false>
 __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
     const c32 *__restrict__ bank, const c32 *__restrict__ blockfft,
     const int64_t *__restrict__ blk_col, const int *__restrict__ blk_ncols, int nblk, int chunk,
     float *__restrict__ plane, int64_t rlen, int halfwidth, const c32 *__restrict__ pw1,
     const c32 *__restrict__ pw2, int numz, int tile_z, int tile_c, Stamp stamp = Stamp(),
-    unsigned short *__restrict__ bound = nullptr)
+    unsigned short *__restrict__ hi = nullptr, unsigned short *__restrict__ lo = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     c32 *lds = reinterpret_cast<c32 *>(smem);
@@ -599,11 +608,10 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
         for (int k = 0; k < 3; k++)
             w2.B[k] = pw2[(w2.NA + k) * P::R3 + (t % P::R3)];
     }
-    float *prow = plane + (size_t) z * (size_t) rlen;
     const int shift = 2 * halfwidth;
-    PlaneStore<P> put(t, PAIR ? 0 : shift);
-    PlaneStore<P, 2> put16(t, BND && !PAIR ? shift : 0);
-    PairStore<P> put2(t, PAIR ? shift : 0, BND);
+    PlaneStore<P> put(t, PAIR || SPLIT ? 0 : shift);
+    PlaneStore<P, 2> put16(t, SPLIT && !PAIR ? shift : 0);
+    PairStore<P> put2(t, PAIR ? shift : 0, SPLIT);
     // every twiddle of passes 1 and 2, formed once and kept in registers for the whole chunk
     c32 W1[P::R1 - 1], W2[P::R2 - 1];
     afft::expand_twiddles<P::R1>(W1, w1);
@@ -620,17 +628,19 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
         stamp.begin(it - b0);
         stamp(0);
         const int blk = ZL ? ia : it;
-        float *out = (ZL ? plane + (size_t) it * (size_t) rlen : prow) + blk_col[blk];
+        const size_t cell0 = (size_t) (ZL ? it : z) * (size_t) rlen + (size_t) blk_col[blk]; // the block's first cell in row z
         const int ncols = blk_ncols[blk];
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, ncols * 4, 0x00020000);
+        float *out = SPLIT ? nullptr : plane + cell0;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, SPLIT ? 0 : ncols * 4, 0x00020000);
+        unsigned short *out_hi = SPLIT ? hi + cell0 : nullptr, *out_lo = SPLIT ? lo + cell0 : nullptr;
+        const __amdgpu_buffer_rsrc_t rsrc_hi = __builtin_amdgcn_make_buffer_rsrc(out_hi, 0, SPLIT ? ncols * 2 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_lo = __builtin_amdgcn_make_buffer_rsrc(out_lo, 0, SPLIT ? ncols * 2 : 0, 0x00020000);
         if constexpr (PAIR)
-            put2.refresh(BND);
+            put2.refresh(SPLIT);
+        else if constexpr (SPLIT)
+            put16.refresh();
         else
             put.refresh();
-        unsigned short *out16 = BND ? bound + (size_t) (ZL ? it : z) * (size_t) rlen + blk_col[blk] : nullptr;
-        const __amdgpu_buffer_rsrc_t rsrc16 = __builtin_amdgcn_make_buffer_rsrc(out16, 0, BND ? ncols * 2 : 0, 0x00020000);
-        if constexpr (BND && !PAIR)
-            put16.refresh();
         // launder the pointer: the loads must stay inside the loop (hoisted, they
         // would pin another 2*R1 registers across the whole transform)
         const c32 *krow_l = ZL ? bank + (size_t) it * P::N : krow;
@@ -675,9 +685,10 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
                 [&](int n, c32 v, c32 w) {
                     const int f = (n - 2 * t) / (P::R1 * P::R2);
                     const float p0 = v.x * v.x + v.y * v.y, p1 = w.x * w.x + w.y * w.y;
-                    put2.powers(rsrc, f, p0, p1);
-                    if constexpr (BND)
-                        put2.bounds(rsrc16, f, p0, p1);
+                    if constexpr (SPLIT)
+                        put2.split(rsrc_hi, rsrc_lo, f, p0, p1);
+                    else
+                        put2.powers(rsrc, f, p0, p1);
                 },
                 stamp);
         } else {
@@ -685,9 +696,10 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
                 lds, load, tw1, tw2, mid,
                 [&](int n, c32 v) {
                     const float pw = v.x * v.x + v.y * v.y;
-                    put(rsrc, n - t, pw);
-                    if constexpr (BND)
-                        put16.bound(rsrc16, n - t, pw);
+                    if constexpr (SPLIT)
+                        put16.split(rsrc_hi, rsrc_lo, n - t, pw);
+                    else
+                        put(rsrc, n - t, pw);
                 },
                 stamp);
         }
@@ -866,15 +878,19 @@ __global__ __launch_bounds__(256) void k_harmsum(
 // ---------------------------------------------------------------------------
 // Harmonic sum over 16-bit upper bounds, exact only where it can matter.
 //
-// `bound` is a second plane of the same shape holding, for every cell, the smallest
-// bfloat16 that is >= the cell's power (bits of the float rounded up to 16).  The kernel
-// walks the columns exactly as k_harmsum does, but reads the bounds: half the bytes.
-// Floating-point addition is monotonic (a <= a', b <= b' => fl(a+b) <= fl(a'+b')), so the
-// sums of the bounds, taken in the same order, bound the exact sums of every stage from
-// above: a row of a wave in which no bound sum crosses its threshold has no crossing.
-// Where one does (a hit, or a cell within 2^-7 of its threshold), the wave recomputes that
-// row from the float plane and compacts the exact crossings: the hits are those of
-// k_harmsum, bit for bit.
+// The plane is kept as two planes of the same shape: `hi` holds the upper 16 bits of every
+// power's float, `lo` the lower 16 (plane generation writes both: k_correlate_rr<.., SPLIT>).
+// For a power p >= 0 with upper half h, (h + 1) << 16 read as a float is greater than p: an
+// upper bound in bfloat16 precision, from half the bytes.  The kernel walks the columns exactly
+// as k_harmsum does, but reads `hi` alone and sums those bounds.  Floating-point addition is
+// monotonic (a <= a', b <= b' => fl(a+b) <= fl(a'+b')), so the sums of the bounds, taken in
+// the same order, bound the exact sums of every stage from above: a row of a wave in which no
+// bound sum crosses its threshold has no crossing.  Where one does (a hit, or a cell within
+// 2^-7 of its threshold) -- or is not <= the threshold at all: an infinite power's bound is
+// a NaN -- the wave recomputes that row from both halves and compacts the exact crossings:
+// the hits are those of k_harmsum on the float plane, bit for bit.
+// Negative powers do not come out of plane generation; a host can write them into the plane
+// (k_split_span sets flags[0] when it sees one), and then every row takes the exact path.
 // ---------------------------------------------------------------------------
 constexpr int harm_stage_of(int i) // i-th sub-harmonic in summing order -> its stage s
 {
@@ -888,40 +904,42 @@ constexpr int harm_num_of(int i) // -> its odd numerator h
     const int s = harm_stage_of(i);
     return 2 * (i + 1 - (1 << (s - 1))) + 1;
 }
-__device__ __forceinline__ float bound_value(unsigned short b) { return __uint_as_float((uint32_t) b << 16); }
-// Smallest bfloat16 >= p for any float: positive values round their magnitude up, negative ones
-// (which plane generation never produces, a host writing the plane may) truncate it.
-__device__ __forceinline__ unsigned short bound_of(float p)
-{
-    const uint32_t b = __float_as_uint(p);
-    return (unsigned short) ((b + ((int32_t) b >= 0 ? 0xFFFFu : 0u)) >> 16);
-}
+__device__ __forceinline__ float bound_value(uint32_t h) { return __uint_as_float((h + 1u) << 16); }
+__device__ __forceinline__ float join_halves(uint32_t h, uint32_t l) { return __uint_as_float((h << 16) | l); }
 
-// bound[i] = bound_of(plane[i]): for planes written by something other than the plane
-// generation kernel (which stores both).
-__global__ __launch_bounds__(256) void k_make_bounds(const float *__restrict__ plane,
-                                                     unsigned short *__restrict__ bound, size_t n)
+// Floats <-> the two planes of halves, for the entry points that hand plane cells to or take
+// them from a host: `n` consecutive cells of `rows` rows, row strides src_stride / rlen.
+__global__ __launch_bounds__(256) void k_split_span(const float *__restrict__ src, int64_t src_stride,
+                                                    unsigned short *__restrict__ hi, unsigned short *__restrict__ lo,
+                                                    int64_t rlen, int64_t n, unsigned int *__restrict__ flags)
 {
-    const size_t stride = (size_t) gridDim.x * 256 * 4;
-    for (size_t i = ((size_t) blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
-        if (i + 4 <= n) {
-            const float4 v = *reinterpret_cast<const float4 *>(plane + i);
-            ushort4 b;
-            b.x = bound_of(v.x), b.y = bound_of(v.y), b.z = bound_of(v.z), b.w = bound_of(v.w);
-            *reinterpret_cast<ushort4 *>(bound + i) = b;
-        } else {
-            for (size_t k = i; k < n; k++)
-                bound[k] = bound_of(plane[k]);
-        }
-    }
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = blockIdx.y;
+    if (i >= n)
+        return;
+    const float p = src[r * src_stride + i];
+    const uint32_t b = __float_as_uint(p);
+    hi[r * rlen + i] = (unsigned short) (b >> 16);
+    lo[r * rlen + i] = (unsigned short) b;
+    if (p < 0.f)
+        flags[0] = 1u; // the bounds of k_harmsum_b hold for p >= 0 only
+}
+__global__ __launch_bounds__(256) void k_join_span(float *__restrict__ dst, int64_t dst_stride,
+                                                   const unsigned short *__restrict__ hi,
+                                                   const unsigned short *__restrict__ lo, int64_t rlen, int64_t n)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = blockIdx.y;
+    if (i < n)
+        dst[r * dst_stride + i] = join_halves(hi[r * rlen + i], lo[r * rlen + i]);
 }
 
 template <int NSTAGES>
 __global__ __launch_bounds__(256) void k_harmsum_b(
-    const float *__restrict__ plane, const unsigned short *__restrict__ bound, int64_t rlen, int numz,
+    const unsigned short *__restrict__ hi, const unsigned short *__restrict__ lo, int64_t rlen, int numz,
     int64_t col0, int64_t ncols, const int64_t *__restrict__ rowoff, const uint32_t *__restrict__ rowchg,
     HarmParams prm, DevHit *__restrict__ hits, unsigned int *__restrict__ count, unsigned int max_hits,
-    int xcd_remap)
+    int xcd_remap, const unsigned int *__restrict__ flags)
 {
     constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
     const int lane = threadIdx.x & 63;
@@ -935,7 +953,7 @@ __global__ __launch_bounds__(256) void k_harmsum_b(
     const int64_t c = (int64_t) tile * 256 + threadIdx.x;
     const bool live = c < ncols;
     const int64_t rind = col0 + (live ? c : 0); // dead lanes read a valid cell
-    uint32_t off[NHS];                          // byte offset of each source column in a row of bounds
+    uint32_t off[NHS];                          // byte offset of each source column in a row of 16-bit halves
     {
         int i = 0;
 #pragma unroll
@@ -944,13 +962,14 @@ __global__ __launch_bounds__(256) void k_harmsum_b(
             for (int h = 1; h < (1 << s); h += 2)
                 off[i++] = (uint32_t) (((rind * h + (1 << (s - 1))) >> s) << 1);
     }
-    const char *bbytes = reinterpret_cast<const char *>(bound);
-    const char *pbytes = reinterpret_cast<const char *>(plane);
-    uint32_t v[NHS]; // the sources' bounds, 16 bits each
+    const char *bbytes = reinterpret_cast<const char *>(hi);
+    const char *lbytes = reinterpret_cast<const char *>(lo);
+    const bool all_exact = flags[0] != 0; // a host has written a negative power into the plane
+    uint32_t v[NHS]; // the sources' upper halves, 16 bits each
     for (int zi = 0; zi < numz; zi++) {
-        float p = bound_value(bound[(size_t) zi * (size_t) rlen + rind]);
+        float p = bound_value(hi[(size_t) zi * (size_t) rlen + rind]);
         const uint32_t chg = NH > 0 ? rowchg[zi] : 0u;
-        int64_t ro[NHS]; // byte offsets of the source rows in the float plane; half of that in the bounds
+        int64_t ro[NHS]; // 4 * rlen * source row: twice the byte offset of that row in a plane of halves
 #pragma unroll
         for (int i = 0; i < NH; i++)
             ro[i] = rowoff[(size_t) zi * NHS + i];
@@ -968,7 +987,7 @@ __global__ __launch_bounds__(256) void k_harmsum_b(
                 v[i] = *reinterpret_cast<const unsigned short *>(bbytes + r + off[i]);
             }
         }
-        bool any = false;
+        bool any = all_exact;
         {
             int i = 0;
 #pragma unroll
@@ -976,13 +995,14 @@ __global__ __launch_bounds__(256) void k_harmsum_b(
                 if (s > 0) {
 #pragma unroll
                     for (int h = 1; h < (1 << s); h += 2)
-                        p += __uint_as_float(v[i++] << 16);
+                        p += bound_value(v[i++]);
                 }
-                any |= live && (p > prm.powcut[s]);
+                any |= live && !(p <= prm.powcut[s]); // a NaN (the bound of an infinite power) counts as a crossing
             }
         }
-        if (__ballot(any)) { // rare: this row again, from the float plane
-            float q = plane[(size_t) zi * (size_t) rlen + rind];
+        if (__ballot(any)) { // rare: this row again, from both halves
+            const size_t fcell = (size_t) zi * (size_t) rlen + rind;
+            float q = join_halves(hi[fcell], lo[fcell]);
             float ps[NSTAGES];
             ps[0] = q;
             // four sources at a time, so that this path's loads do not set the kernel's register count
@@ -997,7 +1017,8 @@ __global__ __launch_bounds__(256) void k_harmsum_b(
                         // group before it has been added
                         uint32_t o = off[i0 + k];
                         asm volatile("" : "+v"(o) : "v"(q));
-                        e[k] = *reinterpret_cast<const float *>(pbytes + ro[i0 + k] + (uint32_t) (2u * o)); // a row is < 4 GB
+                        e[k] = join_halves(*reinterpret_cast<const unsigned short *>(bbytes + (ro[i0 + k] >> 1) + o),
+                                           *reinterpret_cast<const unsigned short *>(lbytes + (ro[i0 + k] >> 1) + o));
                     }
 #pragma unroll
                 for (int k = 0; k < 4; k++)
@@ -1036,10 +1057,10 @@ __global__ __launch_bounds__(256) void k_harmsum_b(
 // registers per extra column: the kernel is bound by load latency at full occupancy.
 template <int NSTAGES, int NC>
 __global__ __launch_bounds__(256) void k_harmsum_bw(
-    const float *__restrict__ plane, const unsigned short *__restrict__ bound, int64_t rlen, int numz,
+    const unsigned short *__restrict__ hi, const unsigned short *__restrict__ lo, int64_t rlen, int numz,
     int64_t col0, int64_t ncols, const int64_t *__restrict__ rowoff, const uint32_t *__restrict__ rowchg,
     HarmParams prm, DevHit *__restrict__ hits, unsigned int *__restrict__ count, unsigned int max_hits,
-    int xcd_remap)
+    int xcd_remap, const unsigned int *__restrict__ flags)
 {
     constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
     constexpr int TILE = 256 * NC;
@@ -1062,8 +1083,8 @@ __global__ __launch_bounds__(256) void k_harmsum_bw(
         live[k] = c0 + lane + 64 * k < ncols;
     // dead lanes read valid cells: the wave's first column, and the plane extends a block past the last searched column
     const int t = live[0] ? lane : 0;
-    const uint32_t toff = 2u * (uint32_t) t; // the lane's byte offset in the wave's first 128 bytes of a row of bounds
-    uint32_t off[NHS]; // byte offset of the first column's source cell in a row of bounds
+    const uint32_t toff = 2u * (uint32_t) t; // the lane's byte offset in the wave's first 128 bytes of a row of halves
+    uint32_t off[NHS]; // byte offset of the first column's source cell in a row of 16-bit halves
     {
         int i = 0;
 #pragma unroll
@@ -1072,9 +1093,10 @@ __global__ __launch_bounds__(256) void k_harmsum_bw(
             for (int h = 1; h < (1 << s); h += 2)
                 off[i++] = (uint32_t) ((((R0 + t) * h + (1 << (s - 1))) >> s) << 1);
     }
-    const char *bbytes = reinterpret_cast<const char *>(bound);
-    const char *pbytes = reinterpret_cast<const char *>(plane);
-    uint32_t v[NC][NHS]; // the sources' bounds, 16 bits each, per column
+    const char *bbytes = reinterpret_cast<const char *>(hi);
+    const char *lbytes = reinterpret_cast<const char *>(lo);
+    const bool all_exact = flags[0] != 0; // a host has written a negative power into the plane
+    uint32_t v[NC][NHS]; // the sources' upper halves, 16 bits each, per column
     for (int zi = 0; zi < numz; zi++) {
         const char *frow = bbytes + 2 * ((size_t) zi * (size_t) rlen + (size_t) R0); // scalar
         uint32_t f[NC];
@@ -1082,7 +1104,7 @@ __global__ __launch_bounds__(256) void k_harmsum_bw(
         for (int k = 0; k < NC; k++)
             f[k] = *reinterpret_cast<const unsigned short *>(frow + toff + 128 * k);
         const uint32_t chg = NH > 0 ? rowchg[zi] : 0u;
-        int64_t ro[NHS]; // byte offsets of the source rows in the float plane; half of that in the bounds
+        int64_t ro[NHS]; // 4 * rlen * source row: twice the byte offset of that row in a plane of halves
 #pragma unroll
         for (int i = 0; i < NH; i++)
             ro[i] = rowoff[(size_t) zi * NHS + i];
@@ -1103,27 +1125,28 @@ __global__ __launch_bounds__(256) void k_harmsum_bw(
         }
         // one column after the other: summed side by side the compiler packs the columns' 16-bit
         // values into shared registers, which costs a wait for its load inside every reload branch
-        bool any = false;
+        bool any = all_exact;
 #pragma unroll
         for (int k = 0; k < NC; k++) {
-            float p = __uint_as_float(f[k] << 16);
+            float p = bound_value(f[k]);
             int i = 0;
 #pragma unroll
             for (int s = 0; s < NSTAGES; s++) {
                 if (s > 0) {
 #pragma unroll
                     for (int h = 1; h < (1 << s); h += 2)
-                        p += __uint_as_float(v[k][i++] << 16);
+                        p += bound_value(v[k][i++]);
                 }
-                any |= live[k] && (p > prm.powcut[s]);
+                any |= live[k] && !(p <= prm.powcut[s]); // a NaN (the bound of an infinite power) counts as a crossing
             }
         }
-        if (__ballot(any)) { // rare: this row again, from the float plane, one column after the other
+        if (__ballot(any)) { // rare: this row again, from both halves, one column after the other
 #pragma unroll
             for (int k = 0; k < NC; k++) {
                 const bool lv = c0 + lane + 64 * k < ncols;
                 const int64_t rind = R0 + t + 64 * k;
-                float q = plane[(size_t) zi * (size_t) rlen + rind];
+                const size_t fcell = (size_t) zi * (size_t) rlen + (size_t) rind;
+                float q = join_halves(hi[fcell], lo[fcell]);
                 float ps[NSTAGES];
                 ps[0] = q;
 #pragma unroll
@@ -1136,8 +1159,9 @@ __global__ __launch_bounds__(256) void k_harmsum_bw(
                             const int sI = harm_stage_of(i0 + j), hI = harm_num_of(i0 + j); // constants once unrolled
                             uint32_t o = off[i0 + j];
                             asm volatile("" : "+v"(o) : "v"(q));
-                            o = 2u * o + 4u * (uint32_t) ((64 * k * hI) >> sI); // a row is < 4 GB
-                            e[j] = *reinterpret_cast<const float *>(pbytes + ro[i0 + j] + o);
+                            o += 2u * (uint32_t) ((64 * k * hI) >> sI);
+                            e[j] = join_halves(*reinterpret_cast<const unsigned short *>(bbytes + (ro[i0 + j] >> 1) + o),
+                                               *reinterpret_cast<const unsigned short *>(lbytes + (ro[i0 + j] >> 1) + o));
                         }
 #pragma unroll
                     for (int j = 0; j < 4; j++)
@@ -1167,6 +1191,36 @@ __global__ __launch_bounds__(256) void k_harmsum_bw(
                 }
             }
         }
+    }
+}
+
+// The summed powers of one stage (accelgpu_summed_block) from a plane kept as halves: the same
+// sums as k_harmsum<.., DUMP>, one thread per column, nothing clever.
+template <int NSTAGES>
+__global__ __launch_bounds__(256) void k_dump_split(
+    const unsigned short *__restrict__ hi, const unsigned short *__restrict__ lo, int64_t rlen, int numz,
+    int64_t col0, int64_t ncols, const int64_t *__restrict__ rowoff, float *__restrict__ dump, int dump_stage)
+{
+    constexpr int NHS = HarmShape<NSTAGES>::NHS;
+    const int64_t c = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncols)
+        return;
+    const int64_t rind = col0 + c;
+    for (int zi = 0; zi < numz; zi++) {
+        const size_t fcell = (size_t) zi * (size_t) rlen + (size_t) rind;
+        float p = join_halves(hi[fcell], lo[fcell]);
+        float keep = p;
+        int i = 0;
+        for (int s = 1; s < NSTAGES; s++) {
+            for (int h = 1; h < (1 << s); h += 2) {
+                const size_t cell = (size_t) (rowoff[(size_t) zi * NHS + i] >> 2) + (size_t) ((rind * h + (1 << (s - 1))) >> s);
+                p += join_halves(hi[cell], lo[cell]);
+                i++;
+            }
+            if (s <= dump_stage)
+                keep = p; // the sum after stage s
+        }
+        dump[(size_t) zi * ncols + c] = keep;
     }
 }
 
@@ -1302,6 +1356,23 @@ __global__ __launch_bounds__(256) void k_block_add_harm(float *__restrict__ bloc
     const int64_t rr = (int64_t) 2 * rlo + j;
     const int64_t src = (rr * h + (1 << (s - 1))) >> s;
     blockpow[(size_t) zi * USELEN + j] += plane[(size_t) zind[zi] * rlen + src];
+}
+
+// the same from a plane kept as halves
+__global__ __launch_bounds__(256) void k_block_add_harm_split(float *__restrict__ blockpow,
+                                                             const unsigned short *__restrict__ hi,
+                                                             const unsigned short *__restrict__ lo,
+                                                             int64_t rlen, int rlo, int s, int h,
+                                                             const int *__restrict__ zind)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int zi = blockIdx.y;
+    if (j >= USELEN)
+        return;
+    const int64_t rr = (int64_t) 2 * rlo + j;
+    const int64_t src = (rr * h + (1 << (s - 1))) >> s;
+    const size_t cell = (size_t) zind[zi] * rlen + src;
+    blockpow[(size_t) zi * USELEN + j] += join_halves(hi[cell], lo[cell]);
 }
 
 // Threshold scan of one block: every cell > powcut becomes a hit.

@@ -178,9 +178,13 @@ struct accelgpu_ctx {
     size_t blockfft_cap = 0;
     float *d_plane = nullptr;
     size_t plane_cap = 0;
-    unsigned short *d_bound = nullptr; // 16-bit upper bounds of the plane's cells (see k_harmsum_b)
-    size_t bound_cap = 0;
-    bool bound_stale = true;           // some plane cell was written without its bound
+    // The plane in its other layout (hs_bound != 0): two planes of 16-bit values, the upper and the
+    // lower halves of every power's float, instead of d_plane.  The harmonic sum reads the upper
+    // halves as bounds (see k_harmsum_b); d_flags[0] is set when a host writes a negative power.
+    bool split = false;
+    unsigned short *d_hi = nullptr, *d_lo = nullptr;
+    size_t hilo_cap = 0;               // cells in each
+    unsigned int *d_flags = nullptr;
     int64_t *d_rowoff = nullptr; // [numz][NH] byte offsets of the sub-harmonic source rows
     size_t rowoff_cap = 0;
     uint32_t *d_rowchg = nullptr; // [numz] bit i: source row of harmonic i differs from row zi-1
@@ -273,7 +277,8 @@ struct accelgpu_ctx {
 namespace {
 
 void free_subbanks(accelgpu_ctx *ctx);
-int reserve_bounds(accelgpu_ctx *ctx);
+bool want_split(const accelgpu_ctx *ctx, int numharmstages);
+int set_search_impl(accelgpu_ctx *ctx, const accelgpu_setup *s, int norm_type, float nph, bool inmem);
 
 int use(accelgpu_ctx *ctx)
 {
@@ -527,16 +532,17 @@ dim3 corr_grid(const Tuning &tn, int numz, int nchunks, int *tile_z, int *tile_c
     return dim3((unsigned) (((tiles + 7) / 8) * 8 * tz * tc));
 }
 
-// d_bound (optional): a second plane of the shape of d_plane that receives the 16-bit upper
-// bound of every power stored (register form only; see k_harmsum_b).
+// Output: rows of `rlen` floats at d_plane, or -- d_hi, d_lo given -- rows of the two planes of
+// 16-bit halves (register form looping over templates only; see k_harmsum_b).
 int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const int64_t *d_col,
-                     const int *d_ncols, float *d_plane, int64_t rlen, unsigned short *d_bound = nullptr)
+                     const int *d_ncols, float *d_plane, int64_t rlen, unsigned short *d_hi = nullptr,
+                     unsigned short *d_lo = nullptr)
 {
     // Register-resident twiddle form for both plans (measured on one device: 3.3 against
     // 5.8 ms per 2^23-point zmax 200 search, 83 against 116 ms per 2^24-point zmax 1200
     // search).  Tuning corr_rr = 0 selects the table form for A/B runs.
     const Tuning &tn = ctx->tune;
-    const bool rr = tn.corr_rr != 0;
+    const bool rr = tn.corr_rr != 0 || d_hi; // (only the register form writes split planes)
     int chunk = corr_chunk(rr ? 16 : 8, ctx->numz, nblk);   // blocks per workgroup (templates in the ZL form)
     if (tn.corr_chunk > 0)
         chunk = tn.corr_chunk;
@@ -552,7 +558,7 @@ int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const i
     // block's spectrum stays in registers: a third less L2->L1 traffic per transform than
     // one template looping over blocks; 2.67 against 2.78 ms on a 201 x 1123 grid, chunks
     // of 16 templates against 8: 2.75, 32: 2.81).  Tuning corr_zl = 0 selects the other loop.
-    const bool zl = tn.corr_zl != 0;
+    const bool zl = tn.corr_zl != 0 || d_hi;
     int tile_z = 0, tile_c = 0;
     dim3 rgrid;
     if (zl) {
@@ -563,18 +569,18 @@ int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const i
     } else {
         rgrid = corr_grid(tn, ctx->numz, (int) grid.y, &tile_z, &tile_c);
     }
-#define LAUNCH_RR(PLAN, ZL, BND, PAIR)                                                         \
-    hipLaunchKernelGGL((accelk::k_correlate_rr<PLAN, false, 16, ZL, afft::NoStamp, BND, PAIR>), rgrid, dim3(PLAN::NT),   \
+#define LAUNCH_RR(PLAN, ZL, SPLIT, PAIR)                                                       \
+    hipLaunchKernelGGL((accelk::k_correlate_rr<PLAN, false, 16, ZL, afft::NoStamp, SPLIT, PAIR>), rgrid, dim3(PLAN::NT),   \
                        PLAN::LDS_BYTES + std::min(std::max(tn.corr_lds, 0), 20000), ctx->stream, ctx->d_bank, d_blockfft, d_col, d_ncols,   \
                        nblk, chunk, d_plane, rlen, ctx->halfwidth, ctx->pw_inv.pw1,            \
-                       ctx->pw_inv.pw2, ctx->numz, tile_z, tile_c, afft::NoStamp(), d_bound)
+                       ctx->pw_inv.pw2, ctx->numz, tile_z, tile_c, afft::NoStamp(), d_hi, d_lo)
     // 8192 points, loop over templates: the last pass hands a thread adjacent outputs, stored two
     // at a time (corr_pair = 0: one at a time, for comparisons; the powers are the same bits)
     const bool pair = tn.corr_pair != 0;
     if (rr && zl && ctx->fftlen == 8192 && pair) {
-        if (d_bound) LAUNCH_RR(P8K, true, true, true);
+        if (d_hi) LAUNCH_RR(P8K, true, true, true);
         else LAUNCH_RR(P8K, true, false, true);
-    } else if (rr && zl && d_bound) {
+    } else if (rr && zl && d_hi) {
         if (ctx->fftlen == 8192) LAUNCH_RR(P8K, true, true, false);
         else LAUNCH_RR(P16K, true, true, false);
     } else if (rr && ctx->fftlen == 8192) {
@@ -597,10 +603,10 @@ int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const i
     return prof_end(ctx, 1, &ep);
 }
 
-// Does the harmonic sum of this search read the 16-bit bounds (k_harmsum_b)?
+// Is the plane kept as two planes of 16-bit halves (and the harmonic sum the bounded one)?
 bool bounds_in_use(const accelgpu_ctx *ctx)
 {
-    return ctx->tune.hs_bound && ctx->d_bound && ctx->inmem && ctx->setup.numharmstages <= 6;
+    return ctx->inmem && ctx->split && ctx->d_hi && ctx->d_lo;
 }
 
 // Where a harmonic-sum launch compacts its threshold crossings.
@@ -682,15 +688,31 @@ int launch_harmsum(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, 
     // (measured on the 2^23-point, zmax 200 plane: 1-2 harmonics 80/78 % of the HBM peak
     // with two pairs against 44/49 % with one column; 4 harmonics 71.5 % with one pair
     // against 60.7 %; 8 harmonics 75 % with one column against 66 % with pairs)
-    if constexpr (!DUMP) {
-        if (bounds_in_use(ctx) && nstages == ctx->setup.numharmstages) {
-            if (ctx->bound_stale) { // the plane was written without its bounds: all of them afresh
-                const size_t n = (size_t) ctx->setup.rlen * ctx->numz;
-                hipLaunchKernelGGL(accelk::k_make_bounds, dim3(256 * 16), dim3(256), 0, ctx->stream, ctx->d_plane,
-                                   ctx->d_bound, n);
-                HIPCHK(hipGetLastError());
-                ctx->bound_stale = false;
+    if (bounds_in_use(ctx) && nstages != ctx->setup.numharmstages) {
+        set_error("harmonic-sum launch for %d stages but the table holds %d", nstages, ctx->setup.numharmstages);
+        return ACCELGPU_ERR_ARG;
+    }
+    if constexpr (DUMP) {
+        if (bounds_in_use(ctx)) {
+            const dim3 grid((unsigned) ((ncols + 255) / 256));
+#define LAUNCH_DUMP(NS)                                                                                   \
+    hipLaunchKernelGGL((accelk::k_dump_split<NS>), grid, dim3(256), 0, ctx->stream, ctx->d_hi, ctx->d_lo, \
+                       ctx->setup.rlen, ctx->numz, col0, ncols, ctx->d_rowoff, dump, dump_stage)
+            switch (nstages) {
+            case 1: LAUNCH_DUMP(1); break;
+            case 2: LAUNCH_DUMP(2); break;
+            case 3: LAUNCH_DUMP(3); break;
+            case 4: LAUNCH_DUMP(4); break;
+            case 5: LAUNCH_DUMP(5); break;
+            default: LAUNCH_DUMP(6); break;
             }
+#undef LAUNCH_DUMP
+            HIPCHK(hipGetLastError());
+            return ACCELGPU_OK;
+        }
+    }
+    if constexpr (!DUMP) {
+        if (bounds_in_use(ctx)) {
             accelk::HarmParams prm;
             for (int i = 0; i < 6; i++)
                 prm.powcut[i] = i < ctx->setup.numharmstages ? ctx->setup.powcut[i] : INFINITY;
@@ -706,16 +728,16 @@ int launch_harmsum(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, 
             }
 #define LAUNCH_HSB(NS)                                                                                    \
     hipLaunchKernelGGL((accelk::k_harmsum_b<NS>), dim3(ntiles), dim3(256), ctx->tune.hs_lds, ctx->stream, \
-                       ctx->d_plane, ctx->d_bound, ctx->setup.rlen, ctx->numz, col0, ncols, ctx->d_rowoff, \
-                       ctx->d_rowchg, prm, out.hits, out.count, cap, remap)
+                       ctx->d_hi, ctx->d_lo, ctx->setup.rlen, ctx->numz, col0, ncols, ctx->d_rowoff, \
+                       ctx->d_rowchg, prm, out.hits, out.count, cap, remap, ctx->d_flags)
 #define LAUNCH_HSBW(NS, NC)                                                                                \
     do {                                                                                                   \
         unsigned nt = (unsigned) ((ncols + 256 * NC - 1) / (256 * NC));                                    \
         if (remap)                                                                                         \
             nt = ((nt + 7) / 8) * 8;                                                                       \
         hipLaunchKernelGGL((accelk::k_harmsum_bw<NS, NC>), dim3(nt), dim3(256), ctx->tune.hs_lds, ctx->stream, \
-                           ctx->d_plane, ctx->d_bound, ctx->setup.rlen, ctx->numz, col0, ncols, ctx->d_rowoff, \
-                           ctx->d_rowchg, prm, out.hits, out.count, cap, remap);                           \
+                           ctx->d_hi, ctx->d_lo, ctx->setup.rlen, ctx->numz, col0, ncols, ctx->d_rowoff, \
+                           ctx->d_rowchg, prm, out.hits, out.count, cap, remap, ctx->d_flags);             \
     } while (0)
             // Several columns per lane (as many times the loads in flight) once there are enough columns
             // to fill the device with that many fewer workgroups; as many columns as keep eight waves
@@ -723,7 +745,7 @@ int launch_harmsum(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, 
             // 4.2 ms (one), 8 harmonics 2.03 against 2.95 ms; 2^21 points, zmax 50: 0.315 against 0.245 ms.
             // hs_bound = 2 / 3 force the one-column / the wide kernel.
             const bool wide = ctx->tune.hs_bound == 3 ||
-                              (ctx->tune.hs_bound == 1 && nstages >= 4 && ncols >= ((int64_t) 1 << 22));
+                              (ctx->tune.hs_bound != 2 && nstages >= 4 && ncols >= ((int64_t) 1 << 22));
             switch (nstages) {
             case 1: if (wide) LAUNCH_HSBW(1, 4); else LAUNCH_HSB(1); break;
             case 2: if (wide) LAUNCH_HSBW(2, 4); else LAUNCH_HSB(2); break;
@@ -808,7 +830,7 @@ int reserve_hits(accelgpu_ctx *ctx, size_t want)
 
 int need_plane(accelgpu_ctx *ctx)
 {
-    if (!ctx->inmem || !ctx->d_plane) {
+    if (!ctx->inmem || !(ctx->split ? ctx->d_hi && ctx->d_lo : ctx->d_plane != nullptr)) {
         set_error("this call needs the in-memory plane: set the search up with accelgpu_set_search()");
         return ACCELGPU_ERR_ARG;
     }
@@ -866,13 +888,11 @@ int queue_fill(accelgpu_ctx *ctx)
     int rc = launch_block_prep(ctx, ctx->nblk_active, ctx->d_blk_lobin, ctx->d_blk_numdata,
                                ctx->d_blockfft);
     if (rc) return rc;
-    // the bounds are written along with the powers by the register form that loops over
-    // templates; any other way of filling the plane leaves them behind
-    const bool with_bounds = bounds_in_use(ctx) && ctx->tune.corr_rr != 0 && ctx->tune.corr_zl != 0;
-    if (!with_bounds)
-        ctx->bound_stale = true;
+    if (bounds_in_use(ctx))
+        return launch_correlate(ctx, ctx->nblk_active, ctx->d_blockfft, ctx->d_blk_col, ctx->d_blk_ncols, nullptr,
+                                ctx->setup.rlen, ctx->d_hi, ctx->d_lo);
     return launch_correlate(ctx, ctx->nblk_active, ctx->d_blockfft, ctx->d_blk_col, ctx->d_blk_ncols,
-                            ctx->d_plane, ctx->setup.rlen, with_bounds ? ctx->d_bound : nullptr);
+                            ctx->d_plane, ctx->setup.rlen);
 }
 
 // Plane generation and harmonic sum of one whole trial, chunk by chunk in ascending r: the
@@ -887,12 +907,10 @@ int queue_fill_and_sum_chunked(accelgpu_ctx *ctx, int chunk_blocks, const HitTar
     for (int s0 = 0; s0 < ctx->nsearch; s0 += chunk_blocks) {
         const int s1 = std::min(s0 + chunk_blocks, ctx->nsearch);
         const int b0 = s0 == 0 ? 0 : ctx->nprepop + s0, b1 = ctx->nprepop + s1; // pre-population blocks go first
-        const bool with_bounds = bounds_in_use(ctx) && ctx->tune.corr_rr != 0 && ctx->tune.corr_zl != 0;
-        if (!with_bounds)
-            ctx->bound_stale = true;
+        const bool halves = bounds_in_use(ctx);
         if ((rc = launch_correlate(ctx, b1 - b0, ctx->d_blockfft + (size_t) b0 * nf, ctx->d_blk_col + b0,
-                                   ctx->d_blk_ncols + b0, ctx->d_plane, ctx->setup.rlen,
-                                   with_bounds ? ctx->d_bound : nullptr)))
+                                   ctx->d_blk_ncols + b0, halves ? nullptr : ctx->d_plane, ctx->setup.rlen,
+                                   halves ? ctx->d_hi : nullptr, halves ? ctx->d_lo : nullptr)))
             return rc;
         if ((rc = launch_harmsum<false>(ctx, ctx->setup.numharmstages, ctx->col0 + (int64_t) s0 * ACCELGPU_USELEN,
                                         (int64_t) (s1 - s0) * ACCELGPU_USELEN, nullptr, 0, out)))
@@ -1236,7 +1254,7 @@ void accelgpu_destroy(accelgpu_ctx *ctx)
     void *dev[] = {ctx->pw_inv.pw1, ctx->pw_inv.pw2, ctx->d_bank, ctx->tw_inv.tw1, ctx->tw_inv.tw2, ctx->tw_fwd_full.tw1,
                    ctx->tw_fwd_full.tw2, ctx->tw_fwd_half.tw1, ctx->tw_fwd_half.tw2,
                    ctx->d_own[0], ctx->d_own[1], ctx->d_own[2], ctx->d_blk_lobin, ctx->d_blk_col, ctx->d_blk_numdata,
-                   ctx->d_blk_ncols, ctx->d_blockfft, ctx->d_plane, ctx->d_bound, ctx->d_rowoff, ctx->d_rowchg, ctx->d_tmp, ctx->d_one_lobin, ctx->d_one_col,
+                   ctx->d_blk_ncols, ctx->d_blockfft, ctx->d_plane, ctx->d_hi, ctx->d_lo, ctx->d_flags, ctx->d_rowoff, ctx->d_rowchg, ctx->d_tmp, ctx->d_one_lobin, ctx->d_one_col,
                    ctx->d_one_numdata, ctx->d_one_ncols, ctx->d_one_blockfft};
     for (void *p : dev)
         if (p) (void) hipFree(p);
@@ -1296,8 +1314,12 @@ int accelgpu_set_tuning(accelgpu_ctx *ctx, const char *name, int value)
         if (!strcmp(name, k.name)) {
             ctx->tune.*(k.field) = value;
             drop_graphs(ctx);
-            if (k.field == &Tuning::hs_bound && value && ctx->have_search && ctx->inmem)
-                return reserve_bounds(ctx);
+            if (k.field == &Tuning::hs_bound && ctx->have_search && ctx->inmem &&
+                want_split(ctx, ctx->setup.numharmstages) != ctx->split) {
+                // the plane changes its layout: set up afresh (an empty plane, as after accelgpu_set_search)
+                const accelgpu_setup again = ctx->setup;
+                return set_search_impl(ctx, &again, ctx->norm_type, ctx->nph, true);
+            }
             return ACCELGPU_OK;
         }
     set_error("accelgpu_set_tuning: no knob named '%s'", name);
@@ -1314,7 +1336,7 @@ int accelgpu_get_tuning(accelgpu_ctx *ctx, const char *name, int *value)
         *value = (int) std::min<size_t>(std::min(ctx->slots[0].cap, ctx->slots[1].cap), 0x7FFFFFFF);
         return ACCELGPU_OK;
     }
-    if (!strcmp(name, "hs_bound_active")) { // read-only: does the current search sum over the 16-bit bounds?
+    if (!strcmp(name, "hs_bound_active")) { // read-only: is the plane kept as halves and summed over its bounds?
         *value = ctx->have_search && bounds_in_use(ctx) ? 1 : 0;
         return ACCELGPU_OK;
     }
@@ -1537,29 +1559,23 @@ int accelgpu_load_fft_device(accelgpu_ctx *ctx, const void *dev, int64_t numbins
 
 namespace {
 
-// The plane of 16-bit bounds beside the float plane, when the knob asks for it and the
-// memory is there (half the plane again).  Without it the harmonic sum reads the float
-// plane alone: same hits.
-int reserve_bounds(accelgpu_ctx *ctx)
+// Which layout an in-memory search of this many stages keeps its plane in: two planes of 16-bit
+// halves for the bounded harmonic sum (hs_bound != 0; every number of stages has a bounded
+// kernel), floats otherwise.  Both take 4 bytes per cell.
+bool want_split(const accelgpu_ctx *ctx, int numharmstages)
 {
-    const size_t plane_elems = (size_t) ctx->setup.rlen * ctx->numz;
-    if (!ctx->tune.hs_bound || !ctx->d_plane || plane_elems == 0 || ctx->setup.numharmstages > 6)
-        return ACCELGPU_OK;
-    if (ctx->bound_cap >= plane_elems && ctx->d_bound)
-        return ACCELGPU_OK;
-    if (ctx->d_bound) HIPCHK(hipFree(ctx->d_bound));
-    ctx->d_bound = nullptr;
-    ctx->bound_cap = 0;
-    ctx->bound_stale = true;
-    size_t free_b = 0, total_b = 0;
-    HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    const size_t want = plane_elems * sizeof(unsigned short) + 64; // the two-column kernel reads 2 bytes past a cell
-    if (want + ((size_t) 4 << 30) > free_b || hipMalloc((void **) &ctx->d_bound, want) != hipSuccess) {
-        (void) hipGetLastError();
-        ctx->d_bound = nullptr; // not an error: the search runs from the float plane
-        return ACCELGPU_OK;
-    }
-    ctx->bound_cap = plane_elems;
+    return ctx->tune.hs_bound != 0 && numharmstages >= 1 && numharmstages <= 6;
+}
+
+int release_plane(accelgpu_ctx *ctx)
+{
+    if (ctx->d_plane) HIPCHK(hipFree(ctx->d_plane));
+    ctx->d_plane = nullptr;
+    ctx->plane_cap = 0;
+    if (ctx->d_hi) HIPCHK(hipFree(ctx->d_hi));
+    if (ctx->d_lo) HIPCHK(hipFree(ctx->d_lo));
+    ctx->d_hi = ctx->d_lo = nullptr;
+    ctx->hilo_cap = 0;
     return ACCELGPU_OK;
 }
 
@@ -1590,7 +1606,8 @@ int set_search_impl(accelgpu_ctx *ctx, const accelgpu_setup *s, int norm_type, f
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     drop_graphs(ctx);
-    const bool same_geometry = ctx->have_search && ctx->inmem && inmem && ctx->setup.rlo == s->rlo &&
+    const bool split = inmem && want_split(ctx, s->numharmstages);
+    const bool same_geometry = ctx->have_search && ctx->inmem && inmem && ctx->split == split && ctx->setup.rlo == s->rlo &&
                                ctx->setup.highestbin == s->highestbin &&
                                ctx->setup.lobin == s->lobin && ctx->setup.zmax == s->zmax;
     ctx->setup = *s;
@@ -1650,16 +1667,8 @@ int set_search_impl(accelgpu_ctx *ctx, const accelgpu_setup *s, int norm_type, f
     ctx->ncols = (int64_t) nsearch * ACCELGPU_USELEN;
     if (!inmem) {
         // standard mode: no plane, no block grid on the device
-        if (ctx->d_plane) {
-            HIPCHK(hipFree(ctx->d_plane));
-            ctx->d_plane = nullptr;
-            ctx->plane_cap = 0;
-        }
-        if (ctx->d_bound) {
-            HIPCHK(hipFree(ctx->d_bound));
-            ctx->d_bound = nullptr;
-            ctx->bound_cap = 0;
-        }
+        if ((rc = release_plane(ctx))) return rc;
+        ctx->split = false;
         ctx->have_search = true;
         return ACCELGPU_OK;
     }
@@ -1689,14 +1698,40 @@ int set_search_impl(accelgpu_ctx *ctx, const accelgpu_setup *s, int norm_type, f
 
     // the plane: zero-filled so that cells below r = 8, which nothing writes, read as 0
     const size_t plane_elems = (size_t) ctx->setup.rlen * ctx->numz;
-    const bool fresh = ctx->plane_cap < plane_elems || !ctx->d_plane;
-    if ((rc = dev_reserve(&ctx->d_plane, &ctx->plane_cap, plane_elems, false, ctx->stream)))
-        return rc;
-    if (fresh || !same_geometry)
-        HIPCHK(hipMemsetAsync(ctx->d_plane, 0, plane_elems * sizeof(float), ctx->stream));
-    if ((rc = reserve_bounds(ctx))) return rc;
-    if (fresh || !same_geometry)
-        ctx->bound_stale = true; // the first search renews them all (cells nothing writes are part of the plane)
+    if (!ctx->d_flags) {
+        HIPCHK(hipMalloc((void **) &ctx->d_flags, 64));
+        HIPCHK(hipMemsetAsync(ctx->d_flags, 0, 64, ctx->stream));
+    }
+    if (split) {
+        if (ctx->d_plane && (rc = release_plane(ctx))) return rc; // the other layout's memory goes first
+        const bool fresh = ctx->hilo_cap < plane_elems || !ctx->d_hi || !ctx->d_lo;
+        if (fresh) {
+            if ((rc = release_plane(ctx))) return rc;
+            // (the several-columns-per-lane sum reads up to 192 cells past a row's searched part: inside
+            // the row; 64 bytes of slack all the same)
+            const size_t bytes = plane_elems * sizeof(unsigned short) + 64;
+            if (hipMalloc((void **) &ctx->d_hi, bytes) != hipSuccess || hipMalloc((void **) &ctx->d_lo, bytes) != hipSuccess) {
+                (void) hipGetLastError();
+                (void) release_plane(ctx);
+                set_error("hipMalloc of the plane (2 x %zu bytes) failed", bytes);
+                return ACCELGPU_ERR_NOMEM;
+            }
+            ctx->hilo_cap = plane_elems;
+        }
+        if (fresh || !same_geometry) {
+            HIPCHK(hipMemsetAsync(ctx->d_hi, 0, plane_elems * sizeof(unsigned short), ctx->stream));
+            HIPCHK(hipMemsetAsync(ctx->d_lo, 0, plane_elems * sizeof(unsigned short), ctx->stream));
+            HIPCHK(hipMemsetAsync(ctx->d_flags, 0, 64, ctx->stream));
+        }
+    } else {
+        if (ctx->d_hi && (rc = release_plane(ctx))) return rc;
+        const bool fresh = ctx->plane_cap < plane_elems || !ctx->d_plane;
+        if ((rc = dev_reserve(&ctx->d_plane, &ctx->plane_cap, plane_elems, false, ctx->stream)))
+            return rc;
+        if (fresh || !same_geometry)
+            HIPCHK(hipMemsetAsync(ctx->d_plane, 0, plane_elems * sizeof(float), ctx->stream));
+    }
+    ctx->split = split;
 
     // sub-harmonic source rows, in summing order (stage ascending, odd harmonic
     // ascending), as byte offsets into the plane: [numz][nh]
@@ -1865,10 +1900,8 @@ int accelgpu_run_launch(accelgpu_ctx *ctx)
         if ((rc = spectrum_ready(ctx, ctx->stream))) return rc;
         const bool whole_grid = ctx->nblk_active == ctx->nblk && ctx->range_first == 0 && ctx->range_count == ctx->nsearch;
         const bool small = ctx->setup.plane_bytes <= ((int64_t) 64 << 20);
-        // (a plane whose bounds are out of date takes the plain path once: the pass that renews
-        // them must not become part of a captured launch)
         if (ctx->tune.use_graph && small && whole_grid && ctx->tune.hs_chunk_blocks == 0 && !ctx->profiling &&
-            ctx->stream == ctx->own_stream && !(bounds_in_use(ctx) && ctx->bound_stale)) {
+            ctx->stream == ctx->own_stream) {
             if ((rc = launch_as_graph(ctx, si))) return rc;
             ctx->plane_serial = sl.serial;
             sl.prefetch = prefetch_hits(ctx, sl);
@@ -2118,7 +2151,16 @@ int accelgpu_fund_to_ffdotplane(accelgpu_ctx *ctx, const float *powers, int32_t 
         return ACCELGPU_ERR_ARG;
     }
     ctx->plane_serial = 0;
-    ctx->bound_stale = true;
+    if (ctx->split) {
+        // through the block buffer: the floats are cut into the two planes of halves on the device
+        if ((rc = upload_block(ctx, powers))) return rc;
+        hipLaunchKernelGGL(accelk::k_split_span, dim3((ACCELGPU_USELEN + 255) / 256, ctx->numz), dim3(256), 0, ctx->stream,
+                           ctx->d_tmp, (int64_t) ACCELGPU_USELEN, ctx->d_hi + col, ctx->d_lo + col, ctx->setup.rlen,
+                           (int64_t) ACCELGPU_USELEN, ctx->d_flags);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        return ACCELGPU_OK;
+    }
     HIPCHK(hipMemcpy2DAsync(ctx->d_plane + col, (size_t) ctx->setup.rlen * sizeof(float), powers,
                             ACCELGPU_USELEN * sizeof(float), ACCELGPU_USELEN * sizeof(float),
                             ctx->numz, hipMemcpyHostToDevice, ctx->stream));
@@ -2151,9 +2193,14 @@ int accelgpu_inmem_add_ffdotpows(accelgpu_ctx *ctx, float *powers, int32_t rlo, 
     int *d_zind = zbuf.p;
     HIPCHK(hipMemcpyAsync(d_zind, zind.data(), zind.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     if ((rc = upload_block(ctx, powers))) return rc;
-    hipLaunchKernelGGL(accelk::k_block_add_harm, dim3((ACCELGPU_USELEN + 255) / 256, ctx->numz),
-                       dim3(256), 0, ctx->stream, ctx->d_tmp, ctx->d_plane, ctx->setup.rlen, rlo, st,
-                       harmnum, d_zind);
+    if (ctx->split)
+        hipLaunchKernelGGL(accelk::k_block_add_harm_split, dim3((ACCELGPU_USELEN + 255) / 256, ctx->numz),
+                           dim3(256), 0, ctx->stream, ctx->d_tmp, ctx->d_hi, ctx->d_lo, ctx->setup.rlen, rlo, st,
+                           harmnum, d_zind);
+    else
+        hipLaunchKernelGGL(accelk::k_block_add_harm, dim3((ACCELGPU_USELEN + 255) / 256, ctx->numz),
+                           dim3(256), 0, ctx->stream, ctx->d_tmp, ctx->d_plane, ctx->setup.rlen, rlo, st,
+                           harmnum, d_zind);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(powers, ctx->d_tmp, (size_t) ctx->numz * ACCELGPU_USELEN * sizeof(float),
                           hipMemcpyDeviceToHost, ctx->stream));
@@ -2220,7 +2267,7 @@ int accelgpu_search_ffdotpows(accelgpu_ctx *ctx, const float *powers, int32_t rl
 
 static int plane_span(accelgpu_ctx *ctx, int zind, int64_t col, int64_t count)
 {
-    if (!ctx->have_search || !ctx->d_plane || !ctx->inmem) {
+    if (!ctx->have_search || !ctx->inmem || !(ctx->split ? ctx->d_hi && ctx->d_lo : ctx->d_plane != nullptr)) {
         set_error("no plane allocated (accelgpu_set_search)");
         return ACCELGPU_ERR_ARG;
     }
@@ -2237,6 +2284,18 @@ int accelgpu_get_plane(accelgpu_ctx *ctx, int zind, int64_t col, int64_t count, 
     int rc = use(ctx);
     if (rc) return rc;
     if ((rc = plane_span(ctx, zind, col, count))) return rc;
+    if (ctx->split) {
+        if (count == 0)
+            return ACCELGPU_OK;
+        if ((rc = dev_reserve(&ctx->d_tmp, &ctx->tmp_cap, (size_t) count, false, ctx->stream))) return rc;
+        const size_t cell = (size_t) zind * ctx->setup.rlen + col;
+        hipLaunchKernelGGL(accelk::k_join_span, dim3((unsigned) ((count + 255) / 256), 1), dim3(256), 0, ctx->stream,
+                           ctx->d_tmp, count, ctx->d_hi + cell, ctx->d_lo + cell, ctx->setup.rlen, count);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out, ctx->d_tmp, (size_t) count * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        return ACCELGPU_OK;
+    }
     HIPCHK(hipMemcpyAsync(out, ctx->d_plane + (size_t) zind * ctx->setup.rlen + col,
                           (size_t) count * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -2249,7 +2308,18 @@ int accelgpu_put_plane(accelgpu_ctx *ctx, int zind, int64_t col, int64_t count, 
     if (rc) return rc;
     if ((rc = plane_span(ctx, zind, col, count))) return rc;
     ctx->plane_serial = 0;
-    ctx->bound_stale = true;
+    if (ctx->split) {
+        if (count == 0)
+            return ACCELGPU_OK;
+        if ((rc = dev_reserve(&ctx->d_tmp, &ctx->tmp_cap, (size_t) count, false, ctx->stream))) return rc;
+        const size_t cell = (size_t) zind * ctx->setup.rlen + col;
+        HIPCHK(hipMemcpyAsync(ctx->d_tmp, in, (size_t) count * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(accelk::k_split_span, dim3((unsigned) ((count + 255) / 256), 1), dim3(256), 0, ctx->stream,
+                           ctx->d_tmp, count, ctx->d_hi + cell, ctx->d_lo + cell, ctx->setup.rlen, count, ctx->d_flags);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        return ACCELGPU_OK;
+    }
     HIPCHK(hipMemcpyAsync(ctx->d_plane + (size_t) zind * ctx->setup.rlen + col, in,
                           (size_t) count * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));

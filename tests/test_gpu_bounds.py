@@ -21,10 +21,14 @@ def gpu():
     g.close()
 
 
-def _hits_by_mode(gpu, modes=(0, 1, 2, 3), max_hits=1 << 22, call=None):
+def _hits_by_mode(gpu, modes=(0, 1, 2, 3), max_hits=1 << 22, call=None, after_mode=None):
+    """The search in every mode of the harmonic sum.  (Switching between 0 and the others changes
+    the plane's layout, which sets the search up afresh: `after_mode` re-applies what that resets.)"""
     out = {}
     for m in modes:
         gpu.set_tuning("hs_bound", m)
+        if after_mode:
+            after_mode()
         out[m] = (call or gpu.run)(max_hits=max_hits)
     return out
 
@@ -80,33 +84,42 @@ def test_dense_hits(gpu):
     _assert_same(res)
 
 
-def test_plane_written_by_the_host_renews_the_bounds(gpu):
-    """put_plane / fund_to_ffdotplane change float cells without their bounds: the next search
-    must notice (it renews all bounds first) -- planted powers far above every threshold, at
-    values whose 16-bit bound equals the power (1024.0), overflows to infinity (3.3e38) or sits
-    one float below a bound (nextafter(2048, 0))."""
+def test_plane_written_by_the_host(gpu):
+    """put_plane writes float cells into whichever layout the plane has -- planted powers far above
+    every threshold, at values whose upper half alone is the power (1024.0), whose bound
+    overflows (3.3e38 -> infinity, infinity -> NaN) or that sit one float below the next upper
+    half (nextafter(2048, 0)) -- and values plane generation never writes but a host may:
+    negative (the bounds hold for p >= 0 only: the kernel must notice) and NaN; neither is a hit,
+    and neither may hide one."""
     N, dt = 1 << 19, 1e-4
     fft = synth.noise_fft(N // 2, 79)
-    setup = gpu.configure(N // 2, N, dt, 20, 16, sigma=6.0, fhi=2000.0)
-    gpu.load_fft(fft)
-    gpu.set_tuning("hs_bound", 1)
-    gpu.fill_plane()
-    before = gpu.search_plane()
-    col0 = 2 * setup.rlo
-    plant = {(3, col0 + 7470 * 2 + 11): np.float32(1024.0),
-             (10, col0 + 7470 * 5 + 4001): np.float32(3.3e38),
-             (17, col0 + 7470 * 9 + 64): np.nextafter(np.float32(2048.0), np.float32(0.0))}
-    # values plane generation never writes but a host may: negative (its bound must round towards
-    # zero, not away from it) and NaN; neither is a hit, and neither may hide one
-    gpu.put_plane(5, col0 + 7470 * 3 + 100, np.array([-1.0000001, np.nan, -3.5e-5], dtype=np.float32))
-    for (zi, col), val in plant.items():
-        gpu.put_plane(zi, col, np.array([val], dtype=np.float32))
-    res = _hits_by_mode(gpu, call=gpu.search_plane)
-    _assert_same(res)
-    got = {(int(h["zind"]), int(h["rind"])): h["power"] for h in res[1] if h["stage"] == 0}
-    for key, val in plant.items():
-        assert key in got and got[key] == val
-    assert len(res[1]) > len(before)
+    res = {}
+    for mode in (0, 1, 2, 3):
+        gpu.set_tuning("hs_bound", mode)
+        setup = gpu.configure(N // 2, N, dt, 20, 16, sigma=6.0, fhi=2000.0)
+        gpu.load_fft(fft)
+        gpu.fill_plane()
+        before = gpu.search_plane()
+        col0 = 2 * setup.rlo
+        plant = {(3, col0 + 7470 * 2 + 11): np.float32(1024.0),
+                 (10, col0 + 7470 * 5 + 4001): np.float32(3.3e38),
+                 (12, col0 + 7470 * 6 + 17): np.float32(np.inf),
+                 (17, col0 + 7470 * 9 + 64): np.nextafter(np.float32(2048.0), np.float32(0.0))}
+        for (zi, col), val in plant.items():
+            gpu.put_plane(zi, col, np.array([val], dtype=np.float32))
+            assert gpu.get_plane(zi, col, 1)[0] == val
+        if mode == 3:
+            res["no negatives"] = gpu.search_plane()
+        neg = np.array([-1.0000001, np.nan, -3.5e-5], dtype=np.float32)
+        gpu.put_plane(5, col0 + 7470 * 3 + 100, neg)
+        assert gpu.get_plane(5, col0 + 7470 * 3 + 100, 3).tobytes() == neg.tobytes()
+        res[mode] = gpu.search_plane()
+        got = {(int(h["zind"]), int(h["rind"])): h["power"] for h in res[mode] if h["stage"] == 0}
+        for key, val in plant.items():
+            assert key in got and got[key] == val
+        assert len(res[mode]) > len(before)
+    _assert_same({m: res[m] for m in (0, 1, 2, 3)})
+    assert len(res["no negatives"]) >= len(res[3])
 
 
 def test_block_range_and_chunked_sum(gpu):
@@ -118,8 +131,7 @@ def test_block_range_and_chunked_sum(gpu):
     _assert_same(whole)
     nb = setup.num_search_blocks
     try:
-        gpu.set_block_range(nb // 3, nb // 2)
-        part = _hits_by_mode(gpu)
+        part = _hits_by_mode(gpu, after_mode=lambda: gpu.set_block_range(nb // 3, nb // 2))
         _assert_same(part)
         want = whole[0][(whole[0]["block"] >= nb // 3) & (whole[0]["block"] < nb // 3 + nb // 2)]
         assert part[0].tobytes() == want.tobytes()
@@ -134,34 +146,36 @@ def test_block_range_and_chunked_sum(gpu):
         gpu.set_tuning("hs_chunk_blocks", 0)
 
 
-def test_table_form_fill_leaves_no_stale_bounds(gpu):
-    """The table-form plane generation (corr_rr = 0) does not store bounds: a bounded search
-    after it renews them; and switching the bounds off and on again between trials with
-    different spectra must not reuse the first trial's bounds."""
+def test_changing_the_layout_between_trials(gpu):
+    """hs_bound 0 <-> 1 changes the plane's layout (floats <-> two planes of halves): the plane is
+    empty afterwards, the next trial fills it again, and nothing of the other layout's trial is
+    left; the table-form plane generation (corr_rr = 0) exists for the float layout only and the
+    knob is ignored in the other."""
     N, dt = 1 << 20, 1e-4
     a = synth.make_fft(N, dt, [dict(f=150.0, z=2.0, amp=0.3, duty=0.1)], seed=82)
     b = synth.make_fft(N, dt, [dict(f=333.3, z=-6.0, amp=0.3, duty=0.1)], seed=83)
-    gpu.configure(N // 2, N, dt, 20, 16, sigma=2.0, fhi=4000.0)
     gpu.set_tuning("hs_bound", 0)
+    gpu.configure(N // 2, N, dt, 20, 16, sigma=2.0, fhi=4000.0)
     gpu.load_fft(a)
     want_a = gpu.run()
     gpu.load_fft(b)
     want_b = gpu.run()
     assert want_a.tobytes() != want_b.tobytes()
     gpu.set_tuning("hs_bound", 1)
+    assert len(gpu.search_plane()) == 0          # the new layout's plane is empty
     gpu.load_fft(a)
     assert gpu.run().tobytes() == want_a.tobytes()
     gpu.set_tuning("hs_bound", 0)
+    assert len(gpu.search_plane()) == 0
     gpu.load_fft(b)
-    gpu.run()                                   # float plane now holds b, the bounds still a
+    assert gpu.run().tobytes() == want_b.tobytes()
     gpu.set_tuning("hs_bound", 1)
-    assert gpu.search_plane().tobytes() == want_b.tobytes()
+    gpu.load_fft(b)
+    assert gpu.run().tobytes() == want_b.tobytes()
     try:
-        gpu.set_tuning("corr_rr", 0)            # (another transform kernel: powers differ in the last bits)
+        gpu.set_tuning("corr_rr", 0)
         gpu.load_fft(a)
-        got = gpu.run()
-        gpu.set_tuning("hs_bound", 0)
-        assert got.tobytes() == gpu.run().tobytes()
+        assert gpu.run().tobytes() == want_a.tobytes()
     finally:
         gpu.set_tuning("corr_rr", 1)
 
