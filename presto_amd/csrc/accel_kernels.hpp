@@ -967,9 +967,10 @@ __global__ __launch_bounds__(256) void k_harmsum_b(
     const bool all_exact = flags[0] != 0; // a host has written a negative power into the plane
     uint32_t v[NHS]; // the sources' upper halves, 16 bits each
     for (int zi = 0; zi < numz; zi++) {
-        float p = bound_value(hi[(size_t) zi * (size_t) rlen + rind]);
+        const uint32_t fh = hi[(size_t) zi * (size_t) rlen + rind];
+        float p = bound_value(fh);
         const uint32_t chg = NH > 0 ? rowchg[zi] : 0u;
-        int64_t ro[NHS]; // 4 * rlen * source row: twice the byte offset of that row in a plane of halves
+        int64_t ro[NHS]; // byte offsets of the sources' rows in a plane of halves (2 * rlen * source row)
 #pragma unroll
         for (int i = 0; i < NH; i++)
             ro[i] = rowoff[(size_t) zi * NHS + i];
@@ -982,7 +983,7 @@ __global__ __launch_bounds__(256) void k_harmsum_b(
 #pragma unroll
         for (int i = 0; i < NH; i++) {
             if (chg & (1u << i)) {
-                const int64_t r = ro[i] >> 1;
+                const int64_t r = ro[i];
                 // kept as loaded; widened where it is added, so that no branch waits for its load
                 v[i] = *reinterpret_cast<const unsigned short *>(bbytes + r + off[i]);
             }
@@ -1000,9 +1001,8 @@ __global__ __launch_bounds__(256) void k_harmsum_b(
                 any |= live && !(p <= prm.powcut[s]); // a NaN (the bound of an infinite power) counts as a crossing
             }
         }
-        if (__ballot(any)) { // rare: this row again, from both halves
-            const size_t fcell = (size_t) zi * (size_t) rlen + rind;
-            float q = join_halves(hi[fcell], lo[fcell]);
+        if (__ballot(any)) { // rare: this row again, exactly: the upper halves are in registers, the lower are fetched
+            float q = join_halves(fh, lo[(size_t) zi * (size_t) rlen + rind]);
             float ps[NSTAGES];
             ps[0] = q;
             // four sources at a time, so that this path's loads do not set the kernel's register count
@@ -1017,8 +1017,11 @@ __global__ __launch_bounds__(256) void k_harmsum_b(
                         // group before it has been added
                         uint32_t o = off[i0 + k];
                         asm volatile("" : "+v"(o) : "v"(q));
-                        e[k] = join_halves(*reinterpret_cast<const unsigned short *>(bbytes + (ro[i0 + k] >> 1) + o),
-                                           *reinterpret_cast<const unsigned short *>(lbytes + (ro[i0 + k] >> 1) + o));
+                        // (with 31 sources the upper half is fetched again: used from its register here, the
+                        // kernel is allotted 111 registers instead of 96, four waves per SIMD instead of five)
+                        const uint32_t h16 = NSTAGES >= 6 ? (uint32_t) *reinterpret_cast<const unsigned short *>(bbytes + ro[i0 + k] + o)
+                                                          : v[i0 + k];
+                        e[k] = join_halves(h16, *reinterpret_cast<const unsigned short *>(lbytes + ro[i0 + k] + o));
                     }
 #pragma unroll
                 for (int k = 0; k < 4; k++)
@@ -1064,6 +1067,7 @@ __global__ __launch_bounds__(256) void k_harmsum_bw(
 {
     constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
     constexpr int TILE = 256 * NC;
+    constexpr int GRP = 7; // sources fetched together on the exact path (8 would cost the 15-source kernel a wave per SIMD)
     const int lane = threadIdx.x & 63;
     unsigned int tile = blockIdx.x;
     if (xcd_remap) {
@@ -1104,7 +1108,7 @@ __global__ __launch_bounds__(256) void k_harmsum_bw(
         for (int k = 0; k < NC; k++)
             f[k] = *reinterpret_cast<const unsigned short *>(frow + toff + 128 * k);
         const uint32_t chg = NH > 0 ? rowchg[zi] : 0u;
-        int64_t ro[NHS]; // 4 * rlen * source row: twice the byte offset of that row in a plane of halves
+        int64_t ro[NHS]; // byte offsets of the sources' rows in a plane of halves (2 * rlen * source row)
 #pragma unroll
         for (int i = 0; i < NH; i++)
             ro[i] = rowoff[(size_t) zi * NHS + i];
@@ -1117,7 +1121,7 @@ __global__ __launch_bounds__(256) void k_harmsum_bw(
         for (int i = 0; i < NH; i++) {
             if (chg & (1u << i)) {
                 const int s = harm_stage_of(i), h = harm_num_of(i);
-                const char *src = bbytes + (ro[i] >> 1) + off[i];
+                const char *src = bbytes + ro[i] + off[i];
 #pragma unroll
                 for (int k = 0; k < NC; k++)
                     v[k][i] = *reinterpret_cast<const unsigned short *>(src + 2 * ((64 * k * h) >> s));
@@ -1140,31 +1144,31 @@ __global__ __launch_bounds__(256) void k_harmsum_bw(
                 any |= live[k] && !(p <= prm.powcut[s]); // a NaN (the bound of an infinite power) counts as a crossing
             }
         }
-        if (__ballot(any)) { // rare: this row again, from both halves, one column after the other
+        if (__ballot(any)) { // rare: this row again, exactly, one column after the other: the upper halves are
+                             // in registers already, the lower halves are fetched
 #pragma unroll
             for (int k = 0; k < NC; k++) {
                 const bool lv = c0 + lane + 64 * k < ncols;
                 const int64_t rind = R0 + t + 64 * k;
                 const size_t fcell = (size_t) zi * (size_t) rlen + (size_t) rind;
-                float q = join_halves(hi[fcell], lo[fcell]);
+                float q = join_halves(f[k], lo[fcell]);
                 float ps[NSTAGES];
                 ps[0] = q;
 #pragma unroll
-                for (int i0 = 0; i0 < NH; i0 += 4) {
-                    float e[4];
+                for (int i0 = 0; i0 < NH; i0 += GRP) { // GRP sources at a time: few registers of its own
+                    float e[GRP];
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
+                    for (int j = 0; j < GRP; j++)
                         if (i0 + j < NH) {
                             // tied to the sum so far: a group's loads start when the group before is added
                             const int sI = harm_stage_of(i0 + j), hI = harm_num_of(i0 + j); // constants once unrolled
                             uint32_t o = off[i0 + j];
                             asm volatile("" : "+v"(o) : "v"(q));
                             o += 2u * (uint32_t) ((64 * k * hI) >> sI);
-                            e[j] = join_halves(*reinterpret_cast<const unsigned short *>(bbytes + (ro[i0 + j] >> 1) + o),
-                                               *reinterpret_cast<const unsigned short *>(lbytes + (ro[i0 + j] >> 1) + o));
+                            e[j] = join_halves(v[k][i0 + j], *reinterpret_cast<const unsigned short *>(lbytes + ro[i0 + j] + o));
                         }
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
+                    for (int j = 0; j < GRP; j++)
                         if (i0 + j < NH) {
                             const int i = i0 + j;
                             q += e[j];

@@ -189,6 +189,8 @@ struct accelgpu_ctx {
     size_t rowoff_cap = 0;
     uint32_t *d_rowchg = nullptr; // [numz] bit i: source row of harmonic i differs from row zi-1
     size_t rowchg_cap = 0;
+    int64_t *d_rowhalf = nullptr; // [numz][NH] the same source rows as byte offsets into a plane of 16-bit halves
+    size_t rowhalf_cap = 0;
 
     // hits
     // Two hit buffers so that one trial's hits can be collected while the next
@@ -728,7 +730,7 @@ int launch_harmsum(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, 
             }
 #define LAUNCH_HSB(NS)                                                                                    \
     hipLaunchKernelGGL((accelk::k_harmsum_b<NS>), dim3(ntiles), dim3(256), ctx->tune.hs_lds, ctx->stream, \
-                       ctx->d_hi, ctx->d_lo, ctx->setup.rlen, ctx->numz, col0, ncols, ctx->d_rowoff, \
+                       ctx->d_hi, ctx->d_lo, ctx->setup.rlen, ctx->numz, col0, ncols, ctx->d_rowhalf, \
                        ctx->d_rowchg, prm, out.hits, out.count, cap, remap, ctx->d_flags)
 #define LAUNCH_HSBW(NS, NC)                                                                                \
     do {                                                                                                   \
@@ -736,7 +738,7 @@ int launch_harmsum(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, 
         if (remap)                                                                                         \
             nt = ((nt + 7) / 8) * 8;                                                                       \
         hipLaunchKernelGGL((accelk::k_harmsum_bw<NS, NC>), dim3(nt), dim3(256), ctx->tune.hs_lds, ctx->stream, \
-                           ctx->d_hi, ctx->d_lo, ctx->setup.rlen, ctx->numz, col0, ncols, ctx->d_rowoff, \
+                           ctx->d_hi, ctx->d_lo, ctx->setup.rlen, ctx->numz, col0, ncols, ctx->d_rowhalf, \
                            ctx->d_rowchg, prm, out.hits, out.count, cap, remap, ctx->d_flags);             \
     } while (0)
             // Several columns per lane (as many times the loads in flight) once there are enough columns
@@ -1254,7 +1256,7 @@ void accelgpu_destroy(accelgpu_ctx *ctx)
     void *dev[] = {ctx->pw_inv.pw1, ctx->pw_inv.pw2, ctx->d_bank, ctx->tw_inv.tw1, ctx->tw_inv.tw2, ctx->tw_fwd_full.tw1,
                    ctx->tw_fwd_full.tw2, ctx->tw_fwd_half.tw1, ctx->tw_fwd_half.tw2,
                    ctx->d_own[0], ctx->d_own[1], ctx->d_own[2], ctx->d_blk_lobin, ctx->d_blk_col, ctx->d_blk_numdata,
-                   ctx->d_blk_ncols, ctx->d_blockfft, ctx->d_plane, ctx->d_hi, ctx->d_lo, ctx->d_flags, ctx->d_rowoff, ctx->d_rowchg, ctx->d_tmp, ctx->d_one_lobin, ctx->d_one_col,
+                   ctx->d_blk_ncols, ctx->d_blockfft, ctx->d_plane, ctx->d_hi, ctx->d_lo, ctx->d_flags, ctx->d_rowoff, ctx->d_rowchg, ctx->d_rowhalf, ctx->d_tmp, ctx->d_one_lobin, ctx->d_one_col,
                    ctx->d_one_numdata, ctx->d_one_ncols, ctx->d_one_blockfft};
     for (void *p : dev)
         if (p) (void) hipFree(p);
@@ -1752,6 +1754,12 @@ int set_search_impl(accelgpu_ctx *ctx, const accelgpu_setup *s, int norm_type, f
         if ((rc = dev_reserve(&ctx->d_rowoff, &ctx->rowoff_cap, tab.size(), false, ctx->stream)))
             return rc;
         HIPCHK(hipMemcpy(ctx->d_rowoff, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        std::vector<int64_t> half(tab.size());
+        for (size_t k = 0; k < tab.size(); k++)
+            half[k] = tab[k] / 2;
+        if ((rc = dev_reserve(&ctx->d_rowhalf, &ctx->rowhalf_cap, half.size(), false, ctx->stream)))
+            return rc;
+        HIPCHK(hipMemcpy(ctx->d_rowhalf, half.data(), half.size() * sizeof(int64_t), hipMemcpyHostToDevice));
         std::vector<uint32_t> chg((size_t) ctx->numz);
         for (int zi = 0; zi < ctx->numz; zi++) {
             uint32_t m = 0;
