@@ -107,13 +107,13 @@ int accelgpu_synchronize(accelgpu_ctx *ctx);
  *                      per (hit buffer, spectrum buffer) as a HIP graph and replayed with one call
  *   corr_lds       0   plane generation: extra bytes of dynamic LDS per workgroup (experiments)
  *   corr_pair      1   plane generation, 8192-point transforms: adjacent outputs stored in pairs
- *   hs_bound       1   harmonic sum over a second plane of 16-bit upper bounds
- *                      of the powers (half the plane's size again, written by plane generation),
- *                      exact from the float plane wherever a bound sum crosses a threshold: the
- *                      same hits from half the bytes.  0: float plane only; 2 / 3: one / several
- *                      columns per lane forced.  Takes effect at the next accelgpu_set_search()
- *                      or at once if a search is set up; silently off when the memory is not there
- *                      ("hs_bound_active", read-only: 1 if the current search uses the bounds)
+ *   hs_bound       1   the in-memory plane is kept as two planes of 16-bit halves of every power's
+ *                      float and the harmonic sum reads the upper halves alone, as upper bounds,
+ *                      fetching the lower halves wherever a bound sum crosses a threshold: the
+ *                      same hits from half the bytes.  0: float plane and float sums; 2 / 3: one /
+ *                      several columns per lane forced.  Changing between 0 and the others sets
+ *                      the search up afresh (an empty plane).  "hs_bound_active" (read-only):
+ *                      1 if the current search keeps its plane as halves
  *   hits_cap   2^20    records in each device hit buffer (set: reallocates both; they
  *                      grow on their own when a search overflows them)
  * ref: none (the reference's only run-time knob is -ncpus). */
