@@ -1101,6 +1101,9 @@ __global__ __launch_bounds__(256) void k_harmsum_bw(
     const char *lbytes = reinterpret_cast<const char *>(lo);
     const bool all_exact = flags[0] != 0; // a host has written a negative power into the plane
     uint32_t v[NC][NHS]; // the sources' upper halves, 16 bits each, per column
+#ifdef HS_DUP_LOADS
+    uint32_t sink = 0;
+#endif
     for (int zi = 0; zi < numz; zi++) {
         const char *frow = bbytes + 2 * ((size_t) zi * (size_t) rlen + (size_t) R0); // scalar
         uint32_t f[NC];
@@ -1125,8 +1128,22 @@ __global__ __launch_bounds__(256) void k_harmsum_bw(
 #pragma unroll
                 for (int k = 0; k < NC; k++)
                     v[k][i] = *reinterpret_cast<const unsigned short *>(src + 2 * ((64 * k * h) >> s));
+#ifdef HS_DUP_LOADS
+                {
+                    uint32_t o2 = off[i];
+                    asm volatile("" : "+v"(o2));
+                    const char *src2 = bbytes + ro[i] + o2;
+#pragma unroll
+                    for (int k = 0; k < NC; k++)
+                        sink += *reinterpret_cast<const unsigned short *>(src2 + 2 * ((64 * k * h) >> s));
+                }
+#endif
             }
         }
+#ifdef HS_DUP_LOADS
+        if (sink == 0xFFFFFFFFu)
+            hits[0].rind = 1;
+#endif
         // one column after the other: summed side by side the compiler packs the columns' 16-bit
         // values into shared registers, which costs a wait for its load inside every reload branch
         bool any = all_exact;
@@ -1192,6 +1209,178 @@ __global__ __launch_bounds__(256) void k_harmsum_bw(
                                 hits[pos] = DevHit{ps[s], ((uint32_t) s << 16) | (uint32_t) zi, rind};
                         }
                     }
+                }
+            }
+        }
+    }
+}
+
+// The same again for many harmonics (31 sources), where registers limit the waves in flight.
+// What a column costs here is its 31 values and little else:
+// * the lanes' source-column offsets are kept as k_harmsum_lean keeps them: for harmonic h/2^s,
+//   (rind*h + 2^(s-1)) >> s = Q + ((B + t*h) >> s) with Q, B from the wave's first column R0 and
+//   t the lane; the lane part is at most 62 cells, a byte offset below 128, four to a register;
+// * the wave-uniform part -- the address of cell Q of the source's row -- is kept across the
+//   LANES of one register pair: lane i holds source i's (plane + its row's byte offset + 2*Q),
+//   read with v_readlane at the moment of a reload.  The row's 31 byte offsets are one vector
+//   load (lane i fetches source i's), requested a row ahead, instead of 62 scalar registers.
+// NC columns 64 apart share all of it, as in k_harmsum_bw.
+template <int NSTAGES, int NC>
+__global__ __launch_bounds__(256) void k_harmsum_bl(
+    const unsigned short *__restrict__ hi, const unsigned short *__restrict__ lo, int64_t rlen, int numz,
+    int64_t col0, int64_t ncols, const int64_t *__restrict__ rowoff, const uint32_t *__restrict__ rowchg,
+    HarmParams prm, DevHit *__restrict__ hits, unsigned int *__restrict__ count, unsigned int max_hits,
+    int xcd_remap, const unsigned int *__restrict__ flags)
+{
+    constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
+    static_assert(NH >= 1 && NH <= 32 && NSTAGES <= 6, "one lane and one mask bit per source");
+    constexpr int NPK = (NH + 3) / 4;
+    constexpr int TILE = 256 * NC;
+    constexpr int GRP = 2; // sources fetched together on the exact path
+    // (addresses rebuilt from lane reads are integers: told to be global memory, or the loads are flat ones)
+    typedef __attribute__((address_space(1))) char gbyte;
+    typedef __attribute__((address_space(1))) unsigned short gushort;
+    const int lane = threadIdx.x & 63;
+    unsigned int tile = blockIdx.x;
+    if (xcd_remap) {
+        const unsigned int per = (gridDim.x + 7) / 8;
+        tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+        if ((int64_t) tile * TILE >= ncols)
+            return;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int64_t c0 = (int64_t) tile * TILE + 64 * NC * wave; // the wave's first column
+    if (c0 >= ncols)
+        return; // nothing to do for the whole wave (the kernel has no barriers)
+    const int64_t R0 = col0 + c0;
+    bool live[NC];
+#pragma unroll
+    for (int k = 0; k < NC; k++)
+        live[k] = c0 + lane + 64 * k < ncols;
+    const int t = live[0] ? lane : 0; // dead lanes shadow the wave's first column
+    const uint32_t toff = 2u * (uint32_t) t;
+    uint32_t pk[NPK];
+#pragma unroll
+    for (int q = 0; q < NPK; q++)
+        pk[q] = 0;
+#pragma unroll
+    for (int i = 0; i < NH; i++) {
+        const int s = harm_stage_of(i), h = harm_num_of(i);
+        const uint32_t B = (uint32_t) ((R0 * h + (1 << (s - 1))) & ((1 << s) - 1));
+        pk[i >> 2] |= (((B + (uint32_t) (t * h)) >> s) << 1) << (8 * (i & 3));
+    }
+    // lane i < NH: source i of the summing order (stage s_i, numerator h_i)
+    const int src_i = lane < NH ? lane : 0;
+    const int s_i = 32 - __clz(src_i + 1);
+    const int h_i = 2 * (src_i + 1 - (1 << (s_i - 1))) + 1;
+    const uint64_t cellq = (uint64_t) reinterpret_cast<uintptr_t>(hi) + 2u * (uint64_t) ((R0 * h_i + (1 << (s_i - 1))) >> s_i);
+    const uint64_t lo_minus_hi = (uint64_t) reinterpret_cast<uintptr_t>(lo) - (uint64_t) reinterpret_cast<uintptr_t>(hi);
+    const char *bbytes = reinterpret_cast<const char *>(hi);
+    const bool all_exact = flags[0] != 0; // a host has written a negative power into the plane
+    uint32_t v[NC][NHS]; // the sources' upper halves, 16 bits each, per column
+    uint32_t roff = 8u * (uint32_t) src_i; // the lane's byte offset in a row of the offsets' table
+    uint32_t tb = toff;
+    int64_t ro_next = rowoff[src_i];
+    for (int zi = 0; zi < numz; zi++) {
+        const uint64_t addr = cellq + (uint64_t) ro_next; // lane i: where source i's cell Q of this row is
+        uint32_t alo = (uint32_t) addr, ahi = (uint32_t) (addr >> 32);
+        // (lane offsets opaque once per row: a load is then scalar row address + 32-bit lane offset, not a
+        // 64-bit address kept in two registers)
+        asm volatile("" : "+v"(roff), "+v"(tb));
+        ro_next = *reinterpret_cast<const int64_t *>(reinterpret_cast<const char *>(rowoff) +
+                                                     (size_t) (zi + 1 < numz ? zi + 1 : zi) * (NHS * 8) + roff);
+        const size_t frow = 2 * ((size_t) zi * (size_t) rlen + (size_t) R0); // scalar: the wave's first fundamental cell
+        uint32_t f[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            f[k] = *reinterpret_cast<const unsigned short *>(bbytes + frow + 128 * k + tb);
+        const uint32_t chg = rowchg[zi];
+        // unpacked at each use: hoisted out of the loop, the unpacked offsets would take the
+        // registers the packing saved
+#pragma unroll
+        for (int q = 0; q < NPK; q++)
+            asm volatile("" : "+v"(pk[q]));
+#pragma unroll
+        for (int i = 0; i < NH; i++) {
+            if (chg & (1u << i)) {
+                const int s = harm_stage_of(i), h = harm_num_of(i);
+                // (opaque here, so that the lane reads stay inside this branch: ahead of the branches
+                // they would be 62 scalar registers again)
+                asm volatile("" : "+v"(alo), "+v"(ahi));
+                const uint64_t base = ((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) ahi, i) << 32) |
+                                      (uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) alo, i);
+                const gbyte *src = (const gbyte *) base + ((pk[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+#pragma unroll
+                for (int k = 0; k < NC; k++)
+                    v[k][i] = *(const gushort *) (src + 2 * ((64 * k * h) >> s));
+            }
+        }
+        bool any = all_exact;
+#pragma unroll
+        for (int k = 0; k < NC; k++) { // one column after the other (see k_harmsum_bw)
+            float p = bound_value(f[k]);
+            int i = 0;
+#pragma unroll
+            for (int s = 0; s < NSTAGES; s++) {
+                if (s > 0) {
+#pragma unroll
+                    for (int h = 1; h < (1 << s); h += 2)
+                        p += bound_value(v[k][i++]);
+                }
+                any |= live[k] && !(p <= prm.powcut[s]); // a NaN (the bound of an infinite power) counts as a crossing
+            }
+        }
+        if (__ballot(any)) { // rare: this row again, exactly, one column after the other, both halves fetched
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                const bool lv = c0 + lane + 64 * k < ncols;
+                const int64_t rind = R0 + t + 64 * k;
+                float q = join_halves(f[k], *reinterpret_cast<const unsigned short *>(
+                                                reinterpret_cast<const char *>(lo) + frow + 128 * k + tb));
+                // a stage's crossings are compacted as soon as its sum is complete (the order k_harmsum
+                // writes them in), so that this path holds no sums beside the running one
+                auto emit = [&](int s, float p) {
+                    const bool hit = lv && (p > prm.powcut[s]);
+                    const unsigned long long mask = __ballot(hit);
+                    if (mask) {
+                        unsigned int base = 0;
+                        const int leader = __ffsll((long long) mask) - 1;
+                        if (lane == leader)
+                            base = atomicAdd(count, (unsigned int) __popcll(mask));
+                        base = __shfl(base, leader);
+                        if (hit) {
+                            const unsigned int pos = base + (unsigned int) __popcll(mask & ((1ull << lane) - 1ull));
+                            if (pos < max_hits)
+                                hits[pos] = DevHit{p, ((uint32_t) s << 16) | (uint32_t) zi, rind};
+                        }
+                    }
+                };
+                emit(0, q);
+#pragma unroll
+                for (int i0 = 0; i0 < NH; i0 += GRP) {
+                    float e[GRP];
+#pragma unroll
+                    for (int j = 0; j < GRP; j++)
+                        if (i0 + j < NH) {
+                            const int i = i0 + j;
+                            const int s = harm_stage_of(i), h = harm_num_of(i); // constants once unrolled
+                            // tied to the sum so far: a group's loads start when the group before is added
+                            asm volatile("" : "+v"(pk[i >> 2]), "+v"(alo), "+v"(ahi) : "v"(q));
+                            const uint64_t base = (((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) ahi, i) << 32) |
+                                                   (uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) alo, i)) +
+                                                  2 * ((64 * k * h) >> s);
+                            const uint32_t o = (pk[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                            e[j] = join_halves(*(const gushort *) ((const gbyte *) base + o),
+                                               *(const gushort *) ((const gbyte *) (base + lo_minus_hi) + o));
+                        }
+#pragma unroll
+                    for (int j = 0; j < GRP; j++)
+                        if (i0 + j < NH) {
+                            const int i = i0 + j;
+                            q += e[j];
+                            if (((i + 2) & (i + 1)) == 0) // the last source of its stage
+                                emit(harm_stage_of(i), q);
+                        }
                 }
             }
         }

@@ -741,6 +741,15 @@ int launch_harmsum(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, 
                            ctx->d_hi, ctx->d_lo, ctx->setup.rlen, ctx->numz, col0, ncols, ctx->d_rowhalf, \
                            ctx->d_rowchg, prm, out.hits, out.count, cap, remap, ctx->d_flags);             \
     } while (0)
+#define LAUNCH_HSBL(NS, NC)                                                                                \
+    do {                                                                                                   \
+        unsigned nt = (unsigned) ((ncols + 256 * NC - 1) / (256 * NC));                                    \
+        if (remap)                                                                                         \
+            nt = ((nt + 7) / 8) * 8;                                                                       \
+        hipLaunchKernelGGL((accelk::k_harmsum_bl<NS, NC>), dim3(nt), dim3(256), ctx->tune.hs_lds, ctx->stream, \
+                           ctx->d_hi, ctx->d_lo, ctx->setup.rlen, ctx->numz, col0, ncols, ctx->d_rowhalf, \
+                           ctx->d_rowchg, prm, out.hits, out.count, cap, remap, ctx->d_flags);             \
+    } while (0)
             // Several columns per lane (as many times the loads in flight) once there are enough columns
             // to fill the device with that many fewer workgroups; as many columns as keep eight waves
             // per SIMD (64 registers).  2^23 points, zmax 200: 16 harmonics 3.49 (two columns) against
@@ -754,10 +763,14 @@ int launch_harmsum(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, 
             case 3: if (wide) LAUNCH_HSBW(3, 4); else LAUNCH_HSB(3); break;
             case 4: if (wide) LAUNCH_HSBW(4, 3); else LAUNCH_HSB(4); break;
             case 5: if (wide) LAUNCH_HSBW(5, 2); else LAUNCH_HSB(5); break;
-            default: LAUNCH_HSB(6); break; // 31 sub-harmonics: 92 registers with one column per lane
+            // 31 sub-harmonics: the register-lean form, four columns per lane (2^24 points, zmax 1200:
+            // 84.5 ms against 101 ms with one column in k_harmsum_b<6> at five waves per SIMD; three
+            // columns 86 ms, two 92 ms, one -- eight waves per SIMD -- 136 ms)
+            default: if (wide) LAUNCH_HSBL(6, 4); else LAUNCH_HSB(6); break;
             }
 #undef LAUNCH_HSB
 #undef LAUNCH_HSBW
+#undef LAUNCH_HSBL
             HIPCHK(hipGetLastError());
             if (timed)
                 return prof_end(ctx, 2, &ep);

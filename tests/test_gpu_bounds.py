@@ -61,30 +61,33 @@ def test_same_hits_for_every_number_of_harmonics(gpu, numharm, zmax):
     _assert_same(res)
 
 
-def test_ragged_end_and_odd_geometry(gpu):
+@pytest.mark.parametrize("numharm", [8, 32])
+def test_ragged_end_and_odd_geometry(gpu, numharm):
     """A search whose column count is not a multiple of the kernels' tiles (dead lanes in the
-    last wave, the second column of a lane beyond the last searched one) and that starts high."""
+    last wave, the later columns of a lane beyond the last searched one) and that starts high."""
     N, dt = 1 << 19, 1e-4
     fft = synth.noise_fft(N // 2, 77)
-    _configure_with_thresholds(gpu, N // 2, N, dt, 10, 8, [9.0, 12.0, 17.0, 26.0], flo=37.0, fhi=1913.0)
+    _configure_with_thresholds(gpu, N // 2, N, dt, 10, numharm, [9.0, 12.0, 17.0, 26.0, 41.0, 68.0], flo=37.0, fhi=1913.0)
     gpu.load_fft(fft)
     res = _hits_by_mode(gpu)
     assert len(res[0]) > 300
     _assert_same(res)
 
 
-def test_dense_hits(gpu):
+@pytest.mark.parametrize("numharm", [16, 32])
+def test_dense_hits(gpu, numharm):
     """A threshold so low that most rows of most waves cross it: the exact path is the common one."""
     N, dt = 1 << 18, 1e-4
     fft = synth.noise_fft(N // 2, 78)
-    _configure_with_thresholds(gpu, N // 2, N, dt, 6, 16, [2.5, 4.0, 7.0, 12.0, 21.0], fhi=2000.0)
+    _configure_with_thresholds(gpu, N // 2, N, dt, 6, numharm, [2.5, 4.0, 7.0, 12.0, 21.0, 38.0], fhi=2000.0)
     gpu.load_fft(fft)
     res = _hits_by_mode(gpu, max_hits=1 << 24)
     assert len(res[0]) > 200000
     _assert_same(res)
 
 
-def test_plane_written_by_the_host(gpu):
+@pytest.mark.parametrize("numharm", [16, 32])
+def test_plane_written_by_the_host(gpu, numharm):
     """put_plane writes float cells into whichever layout the plane has -- planted powers far above
     every threshold, at values whose upper half alone is the power (1024.0), whose bound
     overflows (3.3e38 -> infinity, infinity -> NaN) or that sit one float below the next upper
@@ -93,10 +96,10 @@ def test_plane_written_by_the_host(gpu):
     and neither may hide one."""
     N, dt = 1 << 19, 1e-4
     fft = synth.noise_fft(N // 2, 79)
-    res = {}
+    res, no_neg = {}, {}
     for mode in (0, 1, 2, 3):
         gpu.set_tuning("hs_bound", mode)
-        setup = gpu.configure(N // 2, N, dt, 20, 16, sigma=6.0, fhi=2000.0)
+        setup = gpu.configure(N // 2, N, dt, 20, numharm, sigma=6.0, fhi=2000.0)
         gpu.load_fft(fft)
         gpu.fill_plane()
         before = gpu.search_plane()
@@ -108,8 +111,10 @@ def test_plane_written_by_the_host(gpu):
         for (zi, col), val in plant.items():
             gpu.put_plane(zi, col, np.array([val], dtype=np.float32))
             assert gpu.get_plane(zi, col, 1)[0] == val
-        if mode == 3:
-            res["no negatives"] = gpu.search_plane()
+        # a NaN alone (no negative power yet, so the sums over the bounds are still in use): not a
+        # hit, and the hits of the rows it enters into are those of the float-plane sum
+        gpu.put_plane(7, col0 + 7470 * 4 + 333, np.array([np.nan], dtype=np.float32))
+        no_neg[mode] = gpu.search_plane()
         neg = np.array([-1.0000001, np.nan, -3.5e-5], dtype=np.float32)
         gpu.put_plane(5, col0 + 7470 * 3 + 100, neg)
         assert gpu.get_plane(5, col0 + 7470 * 3 + 100, 3).tobytes() == neg.tobytes()
@@ -118,8 +123,9 @@ def test_plane_written_by_the_host(gpu):
         for key, val in plant.items():
             assert key in got and got[key] == val
         assert len(res[mode]) > len(before)
-    _assert_same({m: res[m] for m in (0, 1, 2, 3)})
-    assert len(res["no negatives"]) >= len(res[3])
+    _assert_same(res)
+    _assert_same(no_neg)
+    assert len(no_neg[3]) >= len(res[3])
 
 
 def test_block_range_and_chunked_sum(gpu):
