@@ -1101,9 +1101,6 @@ __global__ __launch_bounds__(256) void k_harmsum_bw(
     const char *lbytes = reinterpret_cast<const char *>(lo);
     const bool all_exact = flags[0] != 0; // a host has written a negative power into the plane
     uint32_t v[NC][NHS]; // the sources' upper halves, 16 bits each, per column
-#ifdef HS_DUP_LOADS
-    uint32_t sink = 0;
-#endif
     for (int zi = 0; zi < numz; zi++) {
         const char *frow = bbytes + 2 * ((size_t) zi * (size_t) rlen + (size_t) R0); // scalar
         uint32_t f[NC];
@@ -1128,22 +1125,8 @@ __global__ __launch_bounds__(256) void k_harmsum_bw(
 #pragma unroll
                 for (int k = 0; k < NC; k++)
                     v[k][i] = *reinterpret_cast<const unsigned short *>(src + 2 * ((64 * k * h) >> s));
-#ifdef HS_DUP_LOADS
-                {
-                    uint32_t o2 = off[i];
-                    asm volatile("" : "+v"(o2));
-                    const char *src2 = bbytes + ro[i] + o2;
-#pragma unroll
-                    for (int k = 0; k < NC; k++)
-                        sink += *reinterpret_cast<const unsigned short *>(src2 + 2 * ((64 * k * h) >> s));
-                }
-#endif
             }
         }
-#ifdef HS_DUP_LOADS
-        if (sink == 0xFFFFFFFFu)
-            hits[0].rind = 1;
-#endif
         // one column after the other: summed side by side the compiler packs the columns' 16-bit
         // values into shared registers, which costs a wait for its load inside every reload branch
         bool any = all_exact;
