@@ -22,6 +22,10 @@ using afft::c32;
 
 constexpr int USELEN = 7470;
 
+constexpr int kUseLen = 7470; // columns per block (ACCELGPU_USELEN)
+// entries per block and row in the plane of group maxima (see k_prefilter): 1868 whether groups start at column 0 or 2
+constexpr int kGpb = (kUseLen + 2 + 3) >> 2;
+
 struct DevHit {          // 16 bytes, written by k_harmsum
     float power;
     uint32_t stage_zind; // stage << 16 | zind
@@ -322,6 +326,10 @@ __global__ __launch_bounds__(P::NT) void k_block_prep(
         lds, tw1, tw2, [&](int, int a, int) { return d[a]; }, [&](int n, c32 v) { out[n] = v * kScale; });
 }
 
+// |v|^2 as every plane-generation kernel forms it: x*x + (y*y rounded), one fused step -- spelled out,
+// so that all variants of the kernels write the same bits whatever the compiler would contract.
+__device__ __forceinline__ float power_of(c32 v) { return __builtin_fmaf(v.x, v.x, __fmul_rn(v.y, v.y)); }
+
 // ---------------------------------------------------------------------------
 // Stores of one transform's kept outputs into a plane row, through a buffer
 // descriptor over the block's columns [out, out + ncols): the hardware range check
@@ -394,10 +402,25 @@ template <class P> struct PairStore {
     static constexpr int G4 = 4096 / (4 * STEP) > 0 ? 4096 / (4 * STEP) : 1; // f's per offset register, powers
     static constexpr int G2 = 4096 / (2 * STEP) > 0 ? 4096 / (2 * STEP) : 1; // f's per offset register, 16-bit planes
     static constexpr int NG4 = (NF - NEARF + G4 - 1) / G4, NG2 = (NF - NEARF + G2 - 1) / G2;
+    static constexpr int GM = 4096 / (STEP / 2) > 0 ? 4096 / (STEP / 2) : 1; // f's per offset register, group maxima
+    static constexpr int NGM = (NF - NEARF + GM - 1) / GM;
     int near4[NEARF], grp4[NG4 > 0 ? NG4 : 1];
     int near2[NEARF], grp2[NG2 > 0 ? NG2 : 1];
-    __device__ __forceinline__ PairStore(int t, int shift, bool halves)
+    int nearm[NEARF], grpm[NGM > 0 ? NGM : 1]; // byte offsets of the pairs' groups of four (n >> 2) in a block's run of maxima
+    int col0;                                  // column of the thread's first pair
+    __device__ __forceinline__ PairStore(int t, int shift, bool halves, bool maxima = false)
     {
+        col0 = 2 * t - shift;
+#pragma unroll
+        for (int f = 0; f < NEARF; f++) {
+            nearm[f] = maxima ? 2 * (((2 * t + STEP * f) >> 2) - (shift >> 2)) : 0;
+            asm("" : "+v"(nearm[f]));
+        }
+#pragma unroll
+        for (int g = 0; g < NGM; g++) {
+            grpm[g] = maxima ? 2 * (((2 * t + STEP * (NEARF + GM * g)) >> 2) - (shift >> 2)) : 0;
+            asm("" : "+v"(grpm[g]));
+        }
         const int c0 = 2 * t - shift; // column of the thread's first pair
 #pragma unroll
         for (int f = 0; f < NEARF; f++) {
@@ -416,6 +439,27 @@ template <class P> struct PairStore {
             grp2[g] = halves ? 2 * (c0 + STEP * (NEARF + G2 * g)) : 0;
             asm("" : "+v"(grp2[g]));
         }
+    }
+    __device__ __forceinline__ void refresh_maxima()
+    {
+#pragma unroll
+        for (int g = 0; g < NGM; g++)
+            asm volatile("" : "+v"(grpm[g]));
+    }
+    // The largest upper half of the four outputs n >> 2 == const that this lane and its neighbour
+    // (lane ^ 1) hold, into the plane of group maxima; outputs outside the block's columns do not count.
+    __device__ __forceinline__ void maxima(__amdgpu_buffer_rsrc_t mx, int f, float p0, float p1, int ncols) const
+    {
+        float m = fmaxf(p0, p1);
+        if (f < NEARF || STEP * (f + 1) > kUseLen) // pairs that can lie before or behind the block's columns
+            m = (unsigned int) (col0 + STEP * f) < (unsigned int) ncols ? m : 0.f;
+        const float o = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0xB1, 0xF, 0xF, true)); // lane ^ 1
+        m = fmaxf(m, o);
+        const unsigned short h = (unsigned short) (__float_as_uint(m) >> 16);
+        if (f < NEARF)
+            __builtin_amdgcn_raw_buffer_store_b16(h, mx, nearm[f], 0, 0);
+        else
+            __builtin_amdgcn_raw_buffer_store_b16(h, mx, grpm[(f - NEARF) / GM] + (STEP / 2) * ((f - NEARF) % GM), 0, 0);
     }
     __device__ __forceinline__ void refresh(bool halves)
     {
@@ -519,7 +563,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate(
                 else
                     return afft::cmul_conj_v(dreg[a % H], krow_l[P::M1 * a + t]);
             },
-            [&](int n, c32 v) { put(rsrc, n - t, v.x * v.x + v.y * v.y); });
+            [&](int n, c32 v) { put(rsrc, n - t, power_of(v)); });
         __syncthreads(); // pass-3 reads done before the next block's pass-1 writes
     }
 }
@@ -540,14 +584,17 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate(
 // (`hi`, `lo`, each of the plane's shape; `plane` is not used): the harmonic sum reads the upper
 // halves alone -- half the bytes -- and both only where it matters (see k_harmsum_b).
 // PAIR (8192-point plan): the last pass hands a thread adjacent outputs, stored two at a time.
-template <class P, bool KEEPK, int SER, bool ZL = false, class Stamp = afft::NoStamp, bool SPLIT = false, bool PAIR = false>
+template <class P, bool KEEPK, int SER, bool ZL = false, class Stamp = afft::NoStamp, bool SPLIT = false, bool PAIR = false,
+          bool MAXIMA = false>
 __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
     const c32 *__restrict__ bank, const c32 *__restrict__ blockfft,
     const int64_t *__restrict__ blk_col, const int *__restrict__ blk_ncols, int nblk, int chunk,
     float *__restrict__ plane, int64_t rlen, int halfwidth, const c32 *__restrict__ pw1,
     const c32 *__restrict__ pw2, int numz, int tile_z, int tile_c, Stamp stamp = Stamp(),
-    unsigned short *__restrict__ hi = nullptr, unsigned short *__restrict__ lo = nullptr)
+    unsigned short *__restrict__ hi = nullptr, unsigned short *__restrict__ lo = nullptr,
+    unsigned short *__restrict__ mx = nullptr, int64_t mxlen = 0)
 {
+    static_assert(!MAXIMA || (PAIR && SPLIT && ZL), "group maxima come with the paired stores into split planes");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     c32 *lds = reinterpret_cast<c32 *>(smem);
     static_assert(P::B1 == 1, "one pass-1 butterfly per thread");
@@ -611,7 +658,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
     const int shift = 2 * halfwidth;
     PlaneStore<P> put(t, PAIR || SPLIT ? 0 : shift);
     PlaneStore<P, 2> put16(t, SPLIT && !PAIR ? shift : 0);
-    PairStore<P> put2(t, PAIR ? shift : 0, SPLIT);
+    PairStore<P> put2(t, PAIR ? shift : 0, SPLIT, MAXIMA);
     // every twiddle of passes 1 and 2, formed once and kept in registers for the whole chunk
     c32 W1[P::R1 - 1], W2[P::R2 - 1];
     afft::expand_twiddles<P::R1>(W1, w1);
@@ -635,6 +682,12 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
         unsigned short *out_hi = SPLIT ? hi + cell0 : nullptr, *out_lo = SPLIT ? lo + cell0 : nullptr;
         const __amdgpu_buffer_rsrc_t rsrc_hi = __builtin_amdgcn_make_buffer_rsrc(out_hi, 0, SPLIT ? ncols * 2 : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsrc_lo = __builtin_amdgcn_make_buffer_rsrc(out_lo, 0, SPLIT ? ncols * 2 : 0, 0x00020000);
+        // MAXIMA: the block's run of the plane of group maxima in row z (the launch covers the whole block grid:
+        // a block's index is its place in that plane)
+        unsigned short *out_mx = MAXIMA ? mx + (size_t) (ZL ? it : z) * (size_t) mxlen + (size_t) blk * kGpb : nullptr;
+        const __amdgpu_buffer_rsrc_t rsrc_mx = __builtin_amdgcn_make_buffer_rsrc(out_mx, 0, MAXIMA ? kGpb * 2 : 0, 0x00020000);
+        if constexpr (MAXIMA)
+            put2.refresh_maxima();
         if constexpr (PAIR)
             put2.refresh(SPLIT);
         else if constexpr (SPLIT)
@@ -684,18 +737,20 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
                 lds, load, tw1, tw2, mid,
                 [&](int n, c32 v, c32 w) {
                     const int f = (n - 2 * t) / (P::R1 * P::R2);
-                    const float p0 = v.x * v.x + v.y * v.y, p1 = w.x * w.x + w.y * w.y;
+                    const float p0 = power_of(v), p1 = power_of(w);
                     if constexpr (SPLIT)
                         put2.split(rsrc_hi, rsrc_lo, f, p0, p1);
                     else
                         put2.powers(rsrc, f, p0, p1);
+                    if constexpr (MAXIMA)
+                        put2.maxima(rsrc_mx, f, p0, p1, ncols);
                 },
                 stamp);
         } else {
             afft::fft3x<P, +1, SER>(
                 lds, load, tw1, tw2, mid,
                 [&](int n, c32 v) {
-                    const float pw = v.x * v.x + v.y * v.y;
+                    const float pw = power_of(v);
                     if constexpr (SPLIT)
                         put16.split(rsrc_hi, rsrc_lo, n - t, pw);
                     else
@@ -939,8 +994,10 @@ __global__ __launch_bounds__(256) void k_harmsum_b(
     const unsigned short *__restrict__ hi, const unsigned short *__restrict__ lo, int64_t rlen, int numz,
     int64_t col0, int64_t ncols, const int64_t *__restrict__ rowoff, const uint32_t *__restrict__ rowchg,
     HarmParams prm, DevHit *__restrict__ hits, unsigned int *__restrict__ count, unsigned int max_hits,
-    int xcd_remap, const unsigned int *__restrict__ flags)
+    int xcd_remap, const unsigned int *__restrict__ flags, const unsigned int *__restrict__ gate)
 {
+    if (gate && gate[1] == 0)
+        return; // the listed cells were summed instead
     constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
     const int lane = threadIdx.x & 63;
     unsigned int tile = blockIdx.x;
@@ -1063,8 +1120,10 @@ __global__ __launch_bounds__(256) void k_harmsum_bw(
     const unsigned short *__restrict__ hi, const unsigned short *__restrict__ lo, int64_t rlen, int numz,
     int64_t col0, int64_t ncols, const int64_t *__restrict__ rowoff, const uint32_t *__restrict__ rowchg,
     HarmParams prm, DevHit *__restrict__ hits, unsigned int *__restrict__ count, unsigned int max_hits,
-    int xcd_remap, const unsigned int *__restrict__ flags)
+    int xcd_remap, const unsigned int *__restrict__ flags, const unsigned int *__restrict__ gate)
 {
+    if (gate && gate[1] == 0)
+        return; // the listed cells were summed instead
     constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
     constexpr int TILE = 256 * NC;
     constexpr int GRP = 7; // sources fetched together on the exact path (8 would cost the 15-source kernel a wave per SIMD)
@@ -1213,8 +1272,10 @@ __global__ __launch_bounds__(256) void k_harmsum_bl(
     const unsigned short *__restrict__ hi, const unsigned short *__restrict__ lo, int64_t rlen, int numz,
     int64_t col0, int64_t ncols, const int64_t *__restrict__ rowoff, const uint32_t *__restrict__ rowchg,
     HarmParams prm, DevHit *__restrict__ hits, unsigned int *__restrict__ count, unsigned int max_hits,
-    int xcd_remap, const unsigned int *__restrict__ flags)
+    int xcd_remap, const unsigned int *__restrict__ flags, const unsigned int *__restrict__ gate)
 {
+    if (gate && gate[1] == 0)
+        return; // the listed cells were summed instead
     constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
     static_assert(NH >= 1 && NH <= 32 && NSTAGES <= 6, "one lane and one mask bit per source");
     constexpr int NPK = (NH + 3) / 4;
@@ -1364,6 +1425,295 @@ __global__ __launch_bounds__(256) void k_harmsum_bl(
                             if (((i + 2) & (i + 1)) == 0) // the last source of its stage
                                 emit(harm_stage_of(i), q);
                         }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// A coarser bound in front of the sums: the largest upper half of every group of four
+// consecutive columns, and the harmonic sum of those.
+//
+// The groups follow the transforms that wrote the plane: within a block, output n of the
+// transform (column blk_col + n - shift) belongs to group n >> 2.  The plane of maxima has
+// kGpb = 1868 16-bit entries per block and row, entry (b, g) for the columns l = n - shift of
+// block b with (l + A) >> 2 == g, A = shift & 3.  A block of 7470 columns ends (A = 0) or begins
+// (A = 2) with a group of two columns; that entry and its neighbour in the block both stand for
+// the six columns together, so that any run of up to five consecutive columns -- whatever block
+// boundary it crosses -- lies within two consecutive entries.
+//
+// k_prefilter gives a lane one group of four fundamental columns.  For harmonic h/2^s the source
+// columns of those four lie within five consecutive columns, so the larger of two consecutive
+// entries is an upper bound for the source cell of each of the four, and -- floating-point
+// addition being monotonic -- the sums of these bounds, taken in the reference's order, bound
+// every stage's sum of every one of the four columns.  A (row, group) whose bound sums stay at or
+// below the thresholds has no crossing; the others are written to a list, and k_flagged_exact
+// sums their columns exactly from both halves.
+// ---------------------------------------------------------------------------
+struct GroupGrid {
+    int64_t prepop_col0; // first column of the first block below the search region
+    int64_t search_col0; // first column of the first search block
+    int nprepop;         // blocks below the search region
+    int nblk;            // blocks in all
+    int a;               // shift & 3: where groups start relative to a block's first column
+    int64_t mxlen;       // entries per row
+};
+__device__ __forceinline__ uint32_t group_entry_of(const GroupGrid &g, uint32_t c) // c >= prepop_col0
+{
+    const bool srch = c >= (uint32_t) g.search_col0;
+    const uint32_t x = c - (srch ? (uint32_t) g.search_col0 : (uint32_t) g.prepop_col0);
+    const uint32_t b = (srch ? (uint32_t) g.nprepop : 0u) + x / (uint32_t) kUseLen, l = x % (uint32_t) kUseLen;
+    return b * (uint32_t) kGpb + ((l + (uint32_t) g.a) >> 2);
+}
+
+// The plane of maxima from the plane of upper halves: one thread per entry.
+__global__ __launch_bounds__(256) void k_group_max(const unsigned short *__restrict__ hi, int64_t rlen,
+                                                   const int64_t *__restrict__ blk_col, const int *__restrict__ blk_ncols,
+                                                   GroupGrid g, unsigned short *__restrict__ mx)
+{
+    const int lg = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y, zi = blockIdx.z;
+    const unsigned short *cells = hi + (size_t) zi * (size_t) rlen + blk_col[b];
+    const int ncols = min(blk_ncols[b], kUseLen);
+    const bool in = lg < kGpb;
+    unsigned int own = 0;
+    if (in) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int l = 4 * lg - g.a + j;
+            if (l >= 0 && l < ncols)
+                own = max(own, (unsigned int) cells[l]);
+        }
+    }
+    // the six-column pair: both of its entries are neighbours within one wave (entries 0, 1 or 1866, 1867)
+    const int short_g = g.a == 0 ? kGpb - 1 : 0, partner = g.a == 0 ? kGpb - 2 : 1;
+    const unsigned int up = __shfl_down(own, 1), down = __shfl_up(own, 1);
+    if (lg == min(short_g, partner))
+        own = max(own, up);
+    else if (lg == max(short_g, partner))
+        own = max(own, down);
+    if (in)
+        mx[(size_t) zi * (size_t) g.mxlen + (size_t) b * kGpb + lg] = (unsigned short) own;
+}
+
+// After plane generation has written the maxima of the groups n >> 2: a block's two-column group and
+// its neighbour in the block both get the maximum of their six columns.
+__global__ __launch_bounds__(256) void k_group_fix(unsigned short *__restrict__ mx, GroupGrid g, int numz)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x, zi = blockIdx.y;
+    if (b >= g.nblk)
+        return;
+    unsigned short *e = mx + (size_t) zi * (size_t) g.mxlen + (size_t) b * kGpb + (g.a == 0 ? kGpb - 2 : 0);
+    const unsigned short m = max(e[0], e[1]);
+    e[0] = m;
+    e[1] = m;
+}
+
+struct WorkItem {
+    uint32_t zi;
+    uint32_t group; // index of the group of four fundamental columns within the search region
+};
+// work[0..]: the list; ctl[0] = entries wanted (may exceed the capacity), ctl[1] = 1 when the list
+// is of no use (capacity exceeded, or negative powers in the plane) and the plain sum has to run
+template <int NSTAGES>
+__global__ __launch_bounds__(256) void k_prefilter(
+    const unsigned short *__restrict__ mx, int numz, GroupGrid g, int64_t ngroups,
+    const int64_t *__restrict__ rowmx /*[numz][NHS] byte offsets of the source rows in the plane of maxima*/,
+    const uint32_t *__restrict__ rowchg, HarmParams prm, WorkItem *__restrict__ work, unsigned int *__restrict__ ctl,
+    unsigned int work_cap, int xcd_remap, const unsigned int *__restrict__ flags)
+{
+    constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
+    constexpr int LCAP = 2048;
+    __shared__ WorkItem lst[LCAP];
+    __shared__ unsigned int ln, gbase;
+    const int lane = threadIdx.x & 63;
+    unsigned int tile = blockIdx.x;
+    if (xcd_remap) {
+        const unsigned int per = (gridDim.x + 7) / 8;
+        tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+        if ((int64_t) tile * 256 >= ngroups)
+            return;
+    }
+    if (flags[0] != 0) { // negative powers in the plane: the bounds do not hold
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            ctl[1] = 1u;
+        return;
+    }
+    if (threadIdx.x == 0)
+        ln = 0;
+    __syncthreads();
+    const int64_t gid = (int64_t) tile * 256 + threadIdx.x;
+    const bool live = gid < ngroups;
+    const uint32_t gl = live ? (uint32_t) gid : 0u;
+    // the group's columns within the search region
+    const uint32_t sb = gl / (uint32_t) kGpb;
+    const int lg = (int) (gl % (uint32_t) kGpb);
+    const int lfirst = max(4 * lg - g.a, 0), llast = min(4 * lg - g.a + 3, kUseLen - 1);
+    const uint32_t cf = (uint32_t) g.search_col0 + sb * (uint32_t) kUseLen + (uint32_t) lfirst, cl = cf + (uint32_t) (llast - lfirst);
+    const uint32_t foff = 2u * ((uint32_t) (g.nprepop + sb) * (uint32_t) kGpb + (uint32_t) lg); // the group's own entry in a row
+    uint32_t off[NHS]; // byte offset in a row of the first of a source's two entries; bit 0: the second is the next entry
+    bool force = false; // a source whose cells are not covered by two consecutive entries: always listed
+    {
+        int i = 0;
+#pragma unroll
+        for (int s = 1; s < NSTAGES; s++)
+#pragma unroll
+            for (int h = 1; h < (1 << s); h += 2) {
+                const uint32_t s0 = (uint32_t) (((uint64_t) cf * h + (1u << (s - 1))) >> s), s1 = (uint32_t) (((uint64_t) cl * h + (1u << (s - 1))) >> s);
+                uint32_t e0 = 0, d = 3;
+                if (s0 >= (uint32_t) g.prepop_col0) {
+                    e0 = group_entry_of(g, s0);
+                    d = group_entry_of(g, s1) - e0;
+                }
+                if (d == 2) { // three entries: fine when the middle one is a block's short group (it stands for six columns)
+                    const uint32_t mid = (e0 + 1) % (uint32_t) kGpb;
+                    if (g.a == 0 && mid == (uint32_t) kGpb - 1) {
+                        e0 += 1;
+                        d = 1;
+                    } else if (g.a == 2 && mid == 0) {
+                        d = 1;
+                    }
+                }
+                if (d > 1) {
+                    force = true;
+                    e0 = 0;
+                    d = 0;
+                }
+                off[i++] = 2 * e0 + d;
+                __builtin_amdgcn_sched_barrier(0); // one source after the other: interleaved, the set-up sets the register count
+            }
+    }
+    const char *mbytes = reinterpret_cast<const char *>(mx);
+    const int64_t rowb = 2 * g.mxlen;
+    uint32_t v0[NHS], v1[NHS];
+    for (int zi = 0; zi < numz; zi++) {
+        const uint32_t fm = *reinterpret_cast<const unsigned short *>(mbytes + (size_t) zi * (size_t) rowb + foff);
+        const uint32_t chg = NH > 0 ? rowchg[zi] : 0u;
+        int64_t ro[NHS];
+#pragma unroll
+        for (int i = 0; i < NH; i++)
+            ro[i] = rowmx[(size_t) zi * NHS + i];
+#pragma unroll
+        for (int i = 0; i < NH; i++)
+            asm volatile("" : "+v"(off[i]));
+#pragma unroll
+        for (int i = 0; i < NH; i++) {
+            if (chg & (1u << i)) {
+                const char *src = mbytes + ro[i];
+                const uint32_t o0 = off[i] & ~1u, o1 = o0 + ((off[i] & 1u) << 1);
+                v0[i] = *reinterpret_cast<const unsigned short *>(src + o0);
+                v1[i] = *reinterpret_cast<const unsigned short *>(src + o1);
+            }
+        }
+        float p = bound_value(fm);
+        bool any = force;
+        {
+            int i = 0;
+#pragma unroll
+            for (int s = 0; s < NSTAGES; s++) {
+                if (s > 0) {
+#pragma unroll
+                    for (int h = 1; h < (1 << s); h += 2) {
+                        p += bound_value(max(v0[i], v1[i]));
+                        i++;
+                    }
+                }
+                any |= !(p <= prm.powcut[s]); // a NaN (the bound of an infinite power) counts as a crossing
+            }
+        }
+        any = any && live;
+        const unsigned long long mask = __ballot(any);
+        if (mask) { // into the workgroup's list first: one atomic on the global counter per workgroup, not per row
+            unsigned int base = 0;
+            const int leader = __ffsll((long long) mask) - 1;
+            if (lane == leader)
+                base = atomicAdd(&ln, (unsigned int) __popcll(mask));
+            base = __shfl(base, leader);
+            if (any) {
+                const unsigned int pos = base + (unsigned int) __popcll(mask & ((1ull << lane) - 1ull));
+                const WorkItem w{(uint32_t) zi, (uint32_t) gid};
+                if (pos < LCAP) {
+                    lst[pos] = w;
+                } else { // the workgroup's list is full: straight to the global one
+                    const unsigned int gpos = atomicAdd(&ctl[0], 1u);
+                    if (gpos < work_cap)
+                        work[gpos] = w;
+                    else
+                        ctl[1] = 1u;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned int n = min(ln, (unsigned int) LCAP);
+    if (threadIdx.x == 0 && n)
+        gbase = atomicAdd(&ctl[0], n);
+    __syncthreads();
+    for (unsigned int i = threadIdx.x; i < n; i += 256) {
+        if (gbase + i < work_cap)
+            work[gbase + i] = lst[i];
+        else
+            ctl[1] = 1u;
+    }
+}
+
+// The listed (row, group)s, exactly: one thread per column, sums and order as k_harmsum's.
+template <int NSTAGES>
+__global__ __launch_bounds__(256) void k_flagged_exact(
+    const unsigned short *__restrict__ hi, const unsigned short *__restrict__ lo, int64_t rlen, GroupGrid g,
+    const int64_t *__restrict__ rowhalf, HarmParams prm, const WorkItem *__restrict__ work,
+    const unsigned int *__restrict__ ctl, unsigned int work_cap, DevHit *__restrict__ hits,
+    unsigned int *__restrict__ count, unsigned int max_hits)
+{
+    constexpr int NHS = HarmShape<NSTAGES>::NHS;
+    if (ctl[1] != 0)
+        return; // the plain sum runs instead
+    const unsigned int n = min(ctl[0], work_cap);
+    const int lane = threadIdx.x & 63;
+    for (size_t tid = (size_t) blockIdx.x * 256 + threadIdx.x; (tid >> 2) < (((size_t) n + 63) & ~(size_t) 63);
+         tid += (size_t) gridDim.x * 256) { // whole waves stay in the loop for the ballots
+        const size_t e = tid >> 2;
+        const int j = (int) (tid & 3);
+        bool lv = e < n;
+        const WorkItem w = work[lv ? e : 0];
+        const int64_t sb = w.group / kGpb;
+        const int lg = (int) (w.group % kGpb);
+        const int l = 4 * lg - g.a + j;
+        lv = lv && l >= 0 && l < kUseLen;
+        const int64_t rind = g.search_col0 + sb * kUseLen + (lv ? l : max(4 * lg - g.a, 0));
+        const int zi = (int) w.zi;
+        const size_t fcell = (size_t) zi * (size_t) rlen + (size_t) rind;
+        float q = join_halves(hi[fcell], lo[fcell]);
+        float ps[NSTAGES];
+        ps[0] = q;
+        {
+            int i = 0;
+#pragma unroll
+            for (int s = 1; s < NSTAGES; s++) {
+#pragma unroll
+                for (int h = 1; h < (1 << s); h += 2) {
+                    const size_t cell = (size_t) (rowhalf[(size_t) zi * NHS + i] >> 1) + (size_t) ((rind * h + (1 << (s - 1))) >> s);
+                    q += join_halves(hi[cell], lo[cell]);
+                    i++;
+                }
+                ps[s] = q;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NSTAGES; s++) {
+            const bool hit = lv && (ps[s] > prm.powcut[s]);
+            const unsigned long long mask = __ballot(hit);
+            if (mask) {
+                unsigned int base = 0;
+                const int leader = __ffsll((long long) mask) - 1;
+                if (lane == leader)
+                    base = atomicAdd(count, (unsigned int) __popcll(mask));
+                base = __shfl(base, leader);
+                if (hit) {
+                    const unsigned int pos = base + (unsigned int) __popcll(mask & ((1ull << lane) - 1ull));
+                    if (pos < max_hits)
+                        hits[pos] = DevHit{ps[s], ((uint32_t) s << 16) | (uint32_t) zi, rind};
                 }
             }
         }

@@ -190,6 +190,19 @@ struct accelgpu_ctx {
     uint32_t *d_rowchg = nullptr; // [numz] bit i: source row of harmonic i differs from row zi-1
     size_t rowchg_cap = 0;
     int64_t *d_rowhalf = nullptr; // [numz][NH] the same source rows as byte offsets into a plane of 16-bit halves
+    // the coarse bound in front of the bounded sum (k_prefilter): the plane of group maxima, the source
+    // rows as byte offsets into it, the list of (row, group)s to sum exactly and its two control words
+    unsigned short *d_mx = nullptr;
+    size_t mx_cap = 0;
+    int64_t *d_rowmx = nullptr;
+    size_t rowmx_cap = 0;
+    accelk::WorkItem *d_work = nullptr;
+    size_t work_cap = 0;
+    unsigned int *d_ctl = nullptr;
+    accelk::GroupGrid grid{};
+    bool pf_ready = false;    // the three buffers above are sized for the search that is set
+    bool mx_valid = false;    // the maxima describe the plane as it is (written by the last whole plane generation)
+    bool mx_fix_pending = false; // ... once k_group_fix has run
     size_t rowhalf_cap = 0;
 
     // hits
@@ -538,7 +551,7 @@ dim3 corr_grid(const Tuning &tn, int numz, int nchunks, int *tile_z, int *tile_c
 // 16-bit halves (register form looping over templates only; see k_harmsum_b).
 int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const int64_t *d_col,
                      const int *d_ncols, float *d_plane, int64_t rlen, unsigned short *d_hi = nullptr,
-                     unsigned short *d_lo = nullptr)
+                     unsigned short *d_lo = nullptr, unsigned short *d_mx = nullptr, int64_t mxlen = 0)
 {
     // Register-resident twiddle form for both plans (measured on one device: 3.3 against
     // 5.8 ms per 2^23-point zmax 200 search, 83 against 116 ms per 2^24-point zmax 1200
@@ -575,11 +588,17 @@ int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const i
     hipLaunchKernelGGL((accelk::k_correlate_rr<PLAN, false, 16, ZL, afft::NoStamp, SPLIT, PAIR>), rgrid, dim3(PLAN::NT),   \
                        PLAN::LDS_BYTES + std::min(std::max(tn.corr_lds, 0), 20000), ctx->stream, ctx->d_bank, d_blockfft, d_col, d_ncols,   \
                        nblk, chunk, d_plane, rlen, ctx->halfwidth, ctx->pw_inv.pw1,            \
-                       ctx->pw_inv.pw2, ctx->numz, tile_z, tile_c, afft::NoStamp(), d_hi, d_lo)
+                       ctx->pw_inv.pw2, ctx->numz, tile_z, tile_c, afft::NoStamp(), d_hi, d_lo, (unsigned short *) nullptr, (int64_t) 0)
     // 8192 points, loop over templates: the last pass hands a thread adjacent outputs, stored two
     // at a time (corr_pair = 0: one at a time, for comparisons; the powers are the same bits)
     const bool pair = tn.corr_pair != 0;
-    if (rr && zl && ctx->fftlen == 8192 && pair) {
+    if (rr && zl && ctx->fftlen == 8192 && pair && d_hi && d_mx) {
+        // with the largest upper half of every four outputs, for the coarse bound in front of the harmonic sum
+        hipLaunchKernelGGL((accelk::k_correlate_rr<P8K, false, 16, true, afft::NoStamp, true, true, true>), rgrid, dim3(P8K::NT),
+                           P8K::LDS_BYTES + std::min(std::max(tn.corr_lds, 0), 20000), ctx->stream, ctx->d_bank, d_blockfft, d_col,
+                           d_ncols, nblk, chunk, d_plane, rlen, ctx->halfwidth, ctx->pw_inv.pw1, ctx->pw_inv.pw2, ctx->numz,
+                           tile_z, tile_c, afft::NoStamp(), d_hi, d_lo, d_mx, mxlen);
+    } else if (rr && zl && ctx->fftlen == 8192 && pair) {
         if (d_hi) LAUNCH_RR(P8K, true, true, true);
         else LAUNCH_RR(P8K, true, false, true);
     } else if (rr && zl && d_hi) {
@@ -680,6 +699,100 @@ int launch_harmsum_j(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols
     return ACCELGPU_OK;
 }
 
+// The plane of group maxima, the row table into it and the work list, sized for the search that is set.
+int ensure_prefilter(accelgpu_ctx *ctx)
+{
+    if (ctx->pf_ready)
+        return ACCELGPU_OK;
+    const accelgpu_setup &su = ctx->setup;
+    accelk::GroupGrid g{};
+    g.prepop_col0 = ctx->nprepop > 0 ? ctx->h_blk_col[0] : ctx->col0;
+    g.search_col0 = ctx->col0;
+    g.nprepop = ctx->nprepop;
+    g.nblk = ctx->nblk;
+    g.a = (2 * ctx->halfwidth) & 3;
+    g.mxlen = (int64_t) ctx->nblk * accelk::kGpb;
+    ctx->grid = g;
+    int rc;
+    const size_t mx_elems = (size_t) ctx->numz * (size_t) g.mxlen + 64;
+    if ((rc = dev_reserve(&ctx->d_mx, &ctx->mx_cap, mx_elems, false, ctx->stream))) return rc;
+    const int nh = (1 << (su.numharmstages - 1)) - 1;
+    if (nh > 0) {
+        std::vector<int64_t> half((size_t) nh * ctx->numz), tab(half.size());
+        HIPCHK(hipMemcpy(half.data(), ctx->d_rowhalf, half.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < half.size(); k++)
+            tab[k] = half[k] / (2 * su.rlen) * (2 * g.mxlen);
+        if ((rc = dev_reserve(&ctx->d_rowmx, &ctx->rowmx_cap, tab.size(), false, ctx->stream))) return rc;
+        HIPCHK(hipMemcpy(ctx->d_rowmx, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    const size_t ngroups = (size_t) ctx->nsearch * accelk::kGpb;
+    const size_t want = std::max<size_t>((size_t) 1 << 20, (size_t) ctx->numz * ngroups / 64);
+    if ((rc = dev_reserve(&ctx->d_work, &ctx->work_cap, want, false, ctx->stream))) return rc;
+    if (!ctx->d_ctl)
+        HIPCHK(hipMalloc((void **) &ctx->d_ctl, 64));
+    ctx->pf_ready = true;
+    return ACCELGPU_OK;
+}
+
+// Does the coarse bound go in front of the bounded sum of this search?  (The 8192-point paired plane
+// generation writes the group maxima; planes too small to fill the device with a quarter of the
+// lanes, two-stage searches and chunked sums keep the plain bounded sum.)  hs_bound = 4 forces it where
+// it can run at all (the maxima are then taken from the plane if plane generation did not write them).
+bool prefilter_wanted(const accelgpu_ctx *ctx)
+{
+    if (!bounds_in_use(ctx) || ctx->setup.numharmstages < 2 || ctx->tune.hs_chunk_blocks > 0)
+        return false;
+    if (ctx->tune.hs_bound == 4)
+        return true;
+    return ctx->tune.hs_bound == 1 && ctx->setup.numharmstages >= 4 && ctx->ncols >= ((int64_t) 1 << 22);
+}
+bool maxima_from_plane_generation(const accelgpu_ctx *ctx)
+{
+    return prefilter_wanted(ctx) && ctx->fftlen == 8192 && ctx->tune.corr_pair != 0 && ctx->nblk_active == ctx->nblk;
+}
+
+int launch_prefilter(accelgpu_ctx *ctx, int nstages, const accelk::HarmParams &prm, const HitTarget &out, unsigned int cap,
+                     int remap)
+{
+    int rc = ensure_prefilter(ctx);
+    if (rc) return rc;
+    const accelk::GroupGrid &g = ctx->grid;
+    HIPCHK(hipMemsetAsync(ctx->d_ctl, 0, 64, ctx->stream));
+    if (!ctx->mx_valid) { // the plane was not written by a plane generation that keeps the maxima: from the plane
+        const dim3 grid((unsigned) ((accelk::kGpb + 255) / 256), (unsigned) ctx->nblk, (unsigned) ctx->numz);
+        hipLaunchKernelGGL(accelk::k_group_max, grid, dim3(256), 0, ctx->stream, ctx->d_hi, ctx->setup.rlen, ctx->d_blk_col,
+                           ctx->d_blk_ncols, g, ctx->d_mx);
+        ctx->mx_valid = true;
+        ctx->mx_fix_pending = false;
+    } else if (ctx->mx_fix_pending) {
+        hipLaunchKernelGGL(accelk::k_group_fix, dim3((unsigned) ((ctx->nblk + 255) / 256), (unsigned) ctx->numz), dim3(256), 0,
+                           ctx->stream, ctx->d_mx, g, ctx->numz);
+        ctx->mx_fix_pending = false;
+    }
+    const int64_t ngroups = (int64_t) ctx->nsearch * accelk::kGpb;
+    unsigned nt = (unsigned) ((ngroups + 255) / 256);
+    if (remap)
+        nt = ((nt + 7) / 8) * 8;
+    const unsigned int wcap = (unsigned int) std::min<size_t>(ctx->work_cap, 0xFFFFFFFFu);
+#define LAUNCH_PF(NS)                                                                                          \
+    do {                                                                                                       \
+        hipLaunchKernelGGL((accelk::k_prefilter<NS>), dim3(nt), dim3(256), 0, ctx->stream, ctx->d_mx, ctx->numz, g, ngroups, \
+                           ctx->d_rowmx, ctx->d_rowchg, prm, ctx->d_work, ctx->d_ctl, wcap, remap, ctx->d_flags);           \
+        hipLaunchKernelGGL((accelk::k_flagged_exact<NS>), dim3(4096), dim3(256), 0, ctx->stream, ctx->d_hi, ctx->d_lo,       \
+                           ctx->setup.rlen, g, ctx->d_rowhalf, prm, ctx->d_work, ctx->d_ctl, wcap, out.hits, out.count, cap); \
+    } while (0)
+    switch (nstages) {
+    case 2: LAUNCH_PF(2); break;
+    case 3: LAUNCH_PF(3); break;
+    case 4: LAUNCH_PF(4); break;
+    case 5: LAUNCH_PF(5); break;
+    default: LAUNCH_PF(6); break;
+    }
+#undef LAUNCH_PF
+    HIPCHK(hipGetLastError());
+    return ACCELGPU_OK;
+}
+
 template <bool DUMP>
 int launch_harmsum(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, float *dump,
                    int dump_stage, const HitTarget &out, bool timed = true)
@@ -728,10 +841,19 @@ int launch_harmsum(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, 
                 int rc = prof_begin(ctx, 2, &ep);
                 if (rc) return rc;
             }
+            // The coarse bound first: group maxima summed per group of four columns, the
+            // (row, group)s that could cross listed and summed exactly; the plain bounded sum below then
+            // runs only if the list was of no use (its workgroups return at once otherwise).
+            const unsigned int *gate = nullptr;
+            if (prefilter_wanted(ctx) && ctx->nblk_active == ctx->nblk && col0 == ctx->col0 && ncols == ctx->ncols) {
+                int rc = launch_prefilter(ctx, nstages, prm, out, cap, remap);
+                if (rc) return rc;
+                gate = ctx->d_ctl;
+            }
 #define LAUNCH_HSB(NS)                                                                                    \
     hipLaunchKernelGGL((accelk::k_harmsum_b<NS>), dim3(ntiles), dim3(256), ctx->tune.hs_lds, ctx->stream, \
                        ctx->d_hi, ctx->d_lo, ctx->setup.rlen, ctx->numz, col0, ncols, ctx->d_rowhalf, \
-                       ctx->d_rowchg, prm, out.hits, out.count, cap, remap, ctx->d_flags)
+                       ctx->d_rowchg, prm, out.hits, out.count, cap, remap, ctx->d_flags, gate)
 #define LAUNCH_HSBW(NS, NC)                                                                                \
     do {                                                                                                   \
         unsigned nt = (unsigned) ((ncols + 256 * NC - 1) / (256 * NC));                                    \
@@ -739,7 +861,7 @@ int launch_harmsum(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, 
             nt = ((nt + 7) / 8) * 8;                                                                       \
         hipLaunchKernelGGL((accelk::k_harmsum_bw<NS, NC>), dim3(nt), dim3(256), ctx->tune.hs_lds, ctx->stream, \
                            ctx->d_hi, ctx->d_lo, ctx->setup.rlen, ctx->numz, col0, ncols, ctx->d_rowhalf, \
-                           ctx->d_rowchg, prm, out.hits, out.count, cap, remap, ctx->d_flags);             \
+                           ctx->d_rowchg, prm, out.hits, out.count, cap, remap, ctx->d_flags, gate);             \
     } while (0)
 #define LAUNCH_HSBL(NS, NC)                                                                                \
     do {                                                                                                   \
@@ -748,7 +870,7 @@ int launch_harmsum(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, 
             nt = ((nt + 7) / 8) * 8;                                                                       \
         hipLaunchKernelGGL((accelk::k_harmsum_bl<NS, NC>), dim3(nt), dim3(256), ctx->tune.hs_lds, ctx->stream, \
                            ctx->d_hi, ctx->d_lo, ctx->setup.rlen, ctx->numz, col0, ncols, ctx->d_rowhalf, \
-                           ctx->d_rowchg, prm, out.hits, out.count, cap, remap, ctx->d_flags);             \
+                           ctx->d_rowchg, prm, out.hits, out.count, cap, remap, ctx->d_flags, gate);             \
     } while (0)
             // Several columns per lane (as many times the loads in flight) once there are enough columns
             // to fill the device with that many fewer workgroups; as many columns as keep eight waves
@@ -903,9 +1025,18 @@ int queue_fill(accelgpu_ctx *ctx)
     int rc = launch_block_prep(ctx, ctx->nblk_active, ctx->d_blk_lobin, ctx->d_blk_numdata,
                                ctx->d_blockfft);
     if (rc) return rc;
-    if (bounds_in_use(ctx))
+    ctx->mx_valid = false;
+    if (bounds_in_use(ctx)) {
+        if (maxima_from_plane_generation(ctx)) {
+            if ((rc = ensure_prefilter(ctx))) return rc;
+            rc = launch_correlate(ctx, ctx->nblk_active, ctx->d_blockfft, ctx->d_blk_col, ctx->d_blk_ncols, nullptr,
+                                  ctx->setup.rlen, ctx->d_hi, ctx->d_lo, ctx->d_mx, ctx->grid.mxlen);
+            ctx->mx_valid = ctx->mx_fix_pending = rc == ACCELGPU_OK;
+            return rc;
+        }
         return launch_correlate(ctx, ctx->nblk_active, ctx->d_blockfft, ctx->d_blk_col, ctx->d_blk_ncols, nullptr,
                                 ctx->setup.rlen, ctx->d_hi, ctx->d_lo);
+    }
     return launch_correlate(ctx, ctx->nblk_active, ctx->d_blockfft, ctx->d_blk_col, ctx->d_blk_ncols,
                             ctx->d_plane, ctx->setup.rlen);
 }
@@ -1270,7 +1401,7 @@ void accelgpu_destroy(accelgpu_ctx *ctx)
                    ctx->tw_fwd_full.tw2, ctx->tw_fwd_half.tw1, ctx->tw_fwd_half.tw2,
                    ctx->d_own[0], ctx->d_own[1], ctx->d_own[2], ctx->d_blk_lobin, ctx->d_blk_col, ctx->d_blk_numdata,
                    ctx->d_blk_ncols, ctx->d_blockfft, ctx->d_plane, ctx->d_hi, ctx->d_lo, ctx->d_flags, ctx->d_rowoff, ctx->d_rowchg, ctx->d_rowhalf, ctx->d_tmp, ctx->d_one_lobin, ctx->d_one_col,
-                   ctx->d_one_numdata, ctx->d_one_ncols, ctx->d_one_blockfft};
+                   ctx->d_one_numdata, ctx->d_one_ncols, ctx->d_one_blockfft, ctx->d_mx, ctx->d_rowmx, ctx->d_work, ctx->d_ctl};
     for (void *p : dev)
         if (p) (void) hipFree(p);
     free_subbanks(ctx);
@@ -1349,6 +1480,15 @@ int accelgpu_get_tuning(accelgpu_ctx *ctx, const char *name, int *value)
     }
     if (!strcmp(name, "hits_cap")) {
         *value = (int) std::min<size_t>(std::min(ctx->slots[0].cap, ctx->slots[1].cap), 0x7FFFFFFF);
+        return ACCELGPU_OK;
+    }
+    if (!strcmp(name, "pf_listed")) { // read-only: (row, group)s the last coarse bound listed; -1: list of no use
+        unsigned int c[2] = {0, 0};
+        if (ctx->d_ctl) {
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            HIPCHK(hipMemcpy(c, ctx->d_ctl, sizeof(c), hipMemcpyDeviceToHost));
+        }
+        *value = c[1] ? -1 : (int) std::min<unsigned int>(c[0], 0x7FFFFFFFu);
         return ACCELGPU_OK;
     }
     if (!strcmp(name, "hs_bound_active")) { // read-only: is the plane kept as halves and summed over its bounds?
@@ -1591,6 +1731,12 @@ int release_plane(accelgpu_ctx *ctx)
     if (ctx->d_lo) HIPCHK(hipFree(ctx->d_lo));
     ctx->d_hi = ctx->d_lo = nullptr;
     ctx->hilo_cap = 0;
+    if (ctx->d_mx) HIPCHK(hipFree(ctx->d_mx));
+    if (ctx->d_work) HIPCHK(hipFree(ctx->d_work));
+    ctx->d_mx = nullptr;
+    ctx->d_work = nullptr;
+    ctx->mx_cap = ctx->work_cap = 0;
+    ctx->pf_ready = ctx->mx_valid = false;
     return ACCELGPU_OK;
 }
 
@@ -1625,6 +1771,7 @@ int set_search_impl(accelgpu_ctx *ctx, const accelgpu_setup *s, int norm_type, f
     const bool same_geometry = ctx->have_search && ctx->inmem && inmem && ctx->split == split && ctx->setup.rlo == s->rlo &&
                                ctx->setup.highestbin == s->highestbin &&
                                ctx->setup.lobin == s->lobin && ctx->setup.zmax == s->zmax;
+    ctx->pf_ready = ctx->mx_valid = ctx->mx_fix_pending = false;
     ctx->setup = *s;
     ctx->setup.numz = ctx->numz;
     ctx->setup.fftlen = ctx->fftlen;
@@ -2172,6 +2319,7 @@ int accelgpu_fund_to_ffdotplane(accelgpu_ctx *ctx, const float *powers, int32_t 
         return ACCELGPU_ERR_ARG;
     }
     ctx->plane_serial = 0;
+    ctx->mx_valid = false; // the group maxima no longer describe the plane
     if (ctx->split) {
         // through the block buffer: the floats are cut into the two planes of halves on the device
         if ((rc = upload_block(ctx, powers))) return rc;
@@ -2329,6 +2477,7 @@ int accelgpu_put_plane(accelgpu_ctx *ctx, int zind, int64_t col, int64_t count, 
     if (rc) return rc;
     if ((rc = plane_span(ctx, zind, col, count))) return rc;
     ctx->plane_serial = 0;
+    ctx->mx_valid = false; // the group maxima no longer describe the plane
     if (ctx->split) {
         if (count == 0)
             return ACCELGPU_OK;
