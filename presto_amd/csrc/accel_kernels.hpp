@@ -1526,7 +1526,7 @@ __global__ __launch_bounds__(256) void k_prefilter(
     constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
     constexpr int LCAP = 2048;
     __shared__ WorkItem lst[LCAP];
-    __shared__ unsigned int ln, gbase;
+    __shared__ unsigned int ln, gbase, dead;
     const int lane = threadIdx.x & 63;
     unsigned int tile = blockIdx.x;
     if (xcd_remap) {
@@ -1540,8 +1540,10 @@ __global__ __launch_bounds__(256) void k_prefilter(
             ctl[1] = 1u;
         return;
     }
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
         ln = 0;
+        dead = 0;
+    }
     __syncthreads();
     const int64_t gid = (int64_t) tile * 256 + threadIdx.x;
     const bool live = gid < ngroups;
@@ -1630,20 +1632,32 @@ __global__ __launch_bounds__(256) void k_prefilter(
             if (lane == leader)
                 base = atomicAdd(&ln, (unsigned int) __popcll(mask));
             base = __shfl(base, leader);
-            if (any) {
-                const unsigned int pos = base + (unsigned int) __popcll(mask & ((1ull << lane) - 1ull));
-                const WorkItem w{(uint32_t) zi, (uint32_t) gid};
-                if (pos < LCAP) {
-                    lst[pos] = w;
-                } else { // the workgroup's list is full: straight to the global one
-                    const unsigned int gpos = atomicAdd(&ctl[0], 1u);
-                    if (gpos < work_cap)
+            const unsigned int pos = base + (unsigned int) __popcll(mask & ((1ull << lane) - 1ull));
+            const WorkItem w{(uint32_t) zi, (uint32_t) gid};
+            if (any && pos < LCAP)
+                lst[pos] = w;
+            // the workgroup's list is full (a bright signal fills the rows of its columns): the rest of this
+            // wave's row goes straight to the global list, again with one atomic
+            const unsigned long long over = __ballot(any && pos >= LCAP);
+            if (over) {
+                unsigned int gb = 0;
+                const int l2 = __ffsll((long long) over) - 1;
+                if (lane == l2)
+                    gb = atomicAdd(&ctl[0], (unsigned int) __popcll(over));
+                gb = __shfl(gb, l2);
+                if (any && pos >= LCAP) {
+                    const unsigned int gpos = gb + (unsigned int) __popcll(over & ((1ull << lane) - 1ull));
+                    if (gpos < work_cap) {
                         work[gpos] = w;
-                    else
+                    } else { // the global list is full too: the plain sum will run, nothing more to do here
                         ctl[1] = 1u;
+                        dead = 1u;
+                    }
                 }
             }
         }
+        if ((zi & 7) == 7 && dead)
+            break;
     }
     __syncthreads();
     const unsigned int n = min(ln, (unsigned int) LCAP);

@@ -107,6 +107,7 @@ struct Tuning {
     int opt_nt = 512;       // candidate optimisation: threads per workgroup
     int use_graph = 1;      // small searches: one captured graph per launch instead of nine stream operations
     int hs_bound = 1;       // harmonic sum over 16-bit upper bounds of the plane, exact where a bound crosses
+    int pf_list_cap = 0;    // entries of the coarse bound's list of (row, group)s; 0: 1/64 of all of them (tests lower it)
                             // (0: off, float plane only; 1: on; 2 / 3: on, one / two columns per lane forced)
 };
 
@@ -744,7 +745,10 @@ bool prefilter_wanted(const accelgpu_ctx *ctx)
         return false;
     if (ctx->tune.hs_bound == 4)
         return true;
-    return ctx->tune.hs_bound == 1 && ctx->setup.numharmstages >= 4 && ctx->ncols >= ((int64_t) 1 << 22);
+    // 8 or 16 harmonics: with 32 the sum of 32 maxima is too loose a bound (most groups are listed), with
+    // fewer the plain bounded sum has little left to gain
+    return ctx->tune.hs_bound == 1 && ctx->setup.numharmstages >= 4 && ctx->setup.numharmstages <= 5 &&
+           ctx->ncols >= ((int64_t) 1 << 22) && ctx->fftlen == 8192 && ctx->tune.corr_pair != 0;
 }
 bool maxima_from_plane_generation(const accelgpu_ctx *ctx)
 {
@@ -773,7 +777,9 @@ int launch_prefilter(accelgpu_ctx *ctx, int nstages, const accelk::HarmParams &p
     unsigned nt = (unsigned) ((ngroups + 255) / 256);
     if (remap)
         nt = ((nt + 7) / 8) * 8;
-    const unsigned int wcap = (unsigned int) std::min<size_t>(ctx->work_cap, 0xFFFFFFFFu);
+    unsigned int wcap = (unsigned int) std::min<size_t>(ctx->work_cap, 0xFFFFFFFFu);
+    if (ctx->tune.pf_list_cap > 0)
+        wcap = std::min(wcap, (unsigned int) ctx->tune.pf_list_cap);
 #define LAUNCH_PF(NS)                                                                                          \
     do {                                                                                                       \
         hipLaunchKernelGGL((accelk::k_prefilter<NS>), dim3(nt), dim3(256), 0, ctx->stream, ctx->d_mx, ctx->numz, g, ngroups, \
@@ -1096,6 +1102,10 @@ int launch_as_graph(accelgpu_ctx *ctx, int si)
         e.slot = si;
         e.fft = ctx->d_fft;
         e.numbins = ctx->numbins;
+        if (prefilter_wanted(ctx)) { // its buffers are allocated and its table copied outside the capture
+            int rc = ensure_prefilter(ctx);
+            if (rc) return rc;
+        }
         HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
         auto body = [&]() -> int {
             HIPCHK(hipMemsetAsync(sl.d_count, 0, sizeof(unsigned int), ctx->stream));
@@ -1234,7 +1244,7 @@ const TuneName kTuneNames[] = {
     {"hs_j", &Tuning::hs_j},                 {"hs_chunk_blocks", &Tuning::hs_chunk_blocks},
     {"std_table", &Tuning::std_table},       {"std_blocks", &Tuning::std_blocks},
     {"opt_nt", &Tuning::opt_nt},             {"use_graph", &Tuning::use_graph},
-    {"hs_bound", &Tuning::hs_bound},
+    {"hs_bound", &Tuning::hs_bound},         {"pf_list_cap", &Tuning::pf_list_cap},
 };
 
 void tuning_from_env(Tuning *t)
@@ -1489,6 +1499,10 @@ int accelgpu_get_tuning(accelgpu_ctx *ctx, const char *name, int *value)
             HIPCHK(hipMemcpy(c, ctx->d_ctl, sizeof(c), hipMemcpyDeviceToHost));
         }
         *value = c[1] ? -1 : (int) std::min<unsigned int>(c[0], 0x7FFFFFFFu);
+        return ACCELGPU_OK;
+    }
+    if (!strcmp(name, "hs_prefilter_active")) { // read-only: does the coarse bound (group maxima) run in front of the sum?
+        *value = ctx->have_search && prefilter_wanted(ctx) && ctx->nblk_active == ctx->nblk ? 1 : 0;
         return ACCELGPU_OK;
     }
     if (!strcmp(name, "hs_bound_active")) { // read-only: is the plane kept as halves and summed over its bounds?

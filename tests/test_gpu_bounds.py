@@ -1,7 +1,8 @@
-"""The harmonic sum over the plane's 16-bit upper bounds (k_harmsum_b / k_harmsum_bw) against
-the plain sum over the float plane (k_harmsum): the two must return the same hits bit for bit
-on every geometry, through every way the plane can be written, and at the values where a
-rounded-up 16-bit bound behaves specially (equal to its power, overflowing to infinity).
+"""The harmonic sum over the plane's 16-bit upper bounds (k_harmsum_b / k_harmsum_bw / k_harmsum_bl,
+and the coarse bound over the maxima of four columns in front of them: k_prefilter + k_flagged_exact,
+hs_bound = 4) against the plain sum over the float plane (k_harmsum): they must return the same hits
+bit for bit on every geometry, through every way the plane can be written, and at the values where
+a rounded-up 16-bit bound behaves specially (equal to its power, overflowing to infinity).
 The plain sum itself is checked against the CPU oracle in test_gpu_parity.py."""
 import numpy as np
 import pytest
@@ -21,7 +22,7 @@ def gpu():
     g.close()
 
 
-def _hits_by_mode(gpu, modes=(0, 1, 2, 3), max_hits=1 << 22, call=None, after_mode=None):
+def _hits_by_mode(gpu, modes=(0, 1, 2, 3, 4), max_hits=1 << 22, call=None, after_mode=None):
     """The search in every mode of the harmonic sum.  (Switching between 0 and the others changes
     the plane's layout, which sets the search up afresh: `after_mode` re-applies what that resets.)"""
     out = {}
@@ -97,7 +98,7 @@ def test_plane_written_by_the_host(gpu, numharm):
     N, dt = 1 << 19, 1e-4
     fft = synth.noise_fft(N // 2, 79)
     res, no_neg = {}, {}
-    for mode in (0, 1, 2, 3):
+    for mode in (0, 1, 2, 3, 4):
         gpu.set_tuning("hs_bound", mode)
         setup = gpu.configure(N // 2, N, dt, 20, numharm, sigma=6.0, fhi=2000.0)
         gpu.load_fft(fft)
@@ -126,6 +127,40 @@ def test_plane_written_by_the_host(gpu, numharm):
     _assert_same(res)
     _assert_same(no_neg)
     assert len(no_neg[3]) >= len(res[3])
+
+
+def test_coarse_bound_list_overflow_and_long_transforms(gpu):
+    """The coarse bound's list of (row, group)s to sum exactly has a capacity: beyond it the plain
+    bounded sum runs instead (same hits).  And with 16384-point transforms (zmax 1200) plane
+    generation does not write the group maxima: they are taken from the plane."""
+    N, dt = 1 << 19, 1e-4
+    fft = synth.noise_fft(N // 2, 84)
+    _configure_with_thresholds(gpu, N // 2, N, dt, 10, 16, [9.0, 12.0, 17.0, 26.0, 41.0], fhi=2000.0)
+    gpu.load_fft(fft)
+    try:
+        gpu.set_tuning("pf_list_cap", 10)
+        res = _hits_by_mode(gpu, modes=(0, 4))
+        assert gpu.get_tuning("pf_listed") == -1          # the list was of no use
+        _assert_same(res)
+    finally:
+        gpu.set_tuning("pf_list_cap", 0)
+    res = _hits_by_mode(gpu, modes=(0, 4))
+    assert len(res[0]) > 100 and gpu.get_tuning("pf_listed") > 10
+    _assert_same(res)
+    # a threshold so low that a workgroup's own list overflows into the global one
+    _configure_with_thresholds(gpu, N // 2, N, dt, 10, 16, [5.0, 7.0, 10.0, 16.0, 27.0], fhi=2000.0)
+    gpu.load_fft(fft)
+    res = _hits_by_mode(gpu, modes=(0, 4), max_hits=1 << 24)
+    assert len(res[0]) > 20000 and gpu.get_tuning("pf_listed") > 4096
+    _assert_same(res)
+    N = 1 << 20
+    fft = synth.make_fft(N, dt, [dict(f=300.3, z=-40.0, amp=0.3, duty=0.1)], seed=85)
+    setup = gpu.configure(N // 2, N, dt, 1200, 8, sigma=2.0, fhi=4000.0)
+    assert setup.fftlen == 16384
+    gpu.load_fft(fft)
+    res = _hits_by_mode(gpu, modes=(0, 1, 4))
+    assert len(res[0]) > 50 and gpu.get_tuning("pf_listed") >= 0
+    _assert_same(res)
 
 
 def test_block_range_and_chunked_sum(gpu):
