@@ -110,10 +110,19 @@ int accelgpu_synchronize(accelgpu_ctx *ctx);
  *   hs_bound       1   the in-memory plane is kept as two planes of 16-bit halves of every power's
  *                      float and the harmonic sum reads the upper halves alone, as upper bounds,
  *                      fetching the lower halves wherever a bound sum crosses a threshold: the
- *                      same hits from half the bytes.  0: float plane and float sums; 2 / 3: one /
- *                      several columns per lane forced.  Changing between 0 and the others sets
- *                      the search up afresh (an empty plane).  "hs_bound_active" (read-only):
- *                      1 if the current search keeps its plane as halves
+ *                      same hits from half the bytes.  On large planes searched with 8 or 16
+ *                      harmonics (8192-point transforms) a coarser bound runs in front: plane
+ *                      generation also writes the largest upper half of every four columns, the
+ *                      sums of those single out the few (row, four columns) that could cross a
+ *                      threshold, and only these are summed (exactly): the same hits again, from
+ *                      an eighth of the bytes.  0: float plane and float sums; 2 / 3: the bounded
+ *                      sum alone with one / several columns per lane; 4: the coarse bound wherever
+ *                      it can run.  Changing between 0 and the others sets the search up afresh
+ *                      (an empty plane).  Read-only: "hs_bound_active" (1 if the current search
+ *                      keeps its plane as halves), "hs_prefilter_active" (1 if the coarse bound
+ *                      runs), "pf_listed" ((row, four columns) the last search had to sum
+ *                      exactly; -1: too many, the bounded sum ran over the whole plane instead)
+ *   pf_list_cap    0   capacity of that list in entries (0: 1/64 of all there are)
  *   hits_cap   2^20    records in each device hit buffer (set: reallocates both; they
  *                      grow on their own when a search overflows them)
  * ref: none (the reference's only run-time knob is -ncpus). */
