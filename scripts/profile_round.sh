@@ -13,6 +13,7 @@ timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_w
 cd $R
 python3 scripts/pmc_sum.py $OUT/pmc_fetch/f_counter_collection.csv accelk > $OUT/pmc_summary.txt
 python3 scripts/pmc_sum.py $OUT/pmc_write/w_counter_collection.csv accelk >> $OUT/pmc_summary.txt
+python3 scripts/pmc_json.py $OUT/pmc_fetch/f_counter_collection.csv $OUT/pmc_write/w_counter_collection.csv $OUT/pmc_kernels.json
 cat $OUT/trace/t_kernel_stats.csv | cut -c1-220
 cat $OUT/pmc_summary.txt
 grep '"metric"' $OUT/bench_under_trace.log | cut -c1-600
