@@ -123,6 +123,9 @@ int accelgpu_synchronize(accelgpu_ctx *ctx);
  *                      runs), "pf_listed" ((row, four columns) the last search had to sum
  *                      exactly; -1: too many, the bounded sum ran over the whole plane instead)
  *   pf_list_cap    0   capacity of that list in entries (0: 1/64 of all there are)
+ *   pf_pairs       1   with up to 8 harmonics the coarse bound's kernel gives a lane two adjacent
+ *                      groups of four columns (one 8-byte load per source and lane instead of four
+ *                      16-bit loads); 2: with 16 harmonics too; 0: never
  *   hits_cap   2^20    records in each device hit buffer (set: reallocates both; they
  *                      grow on their own when a search overflows them)
  * ref: none (the reference's only run-time knob is -ncpus). */

@@ -1517,7 +1517,7 @@ struct WorkItem {
 // work[0..]: the list; ctl[0] = entries wanted (may exceed the capacity), ctl[1] = 1 when the list
 // is of no use (capacity exceeded, or negative powers in the plane) and the plain sum has to run
 template <int NSTAGES>
-__global__ __launch_bounds__(256) void k_prefilter(
+__global__ __launch_bounds__(256) void k_prefilter_lanes(
     const unsigned short *__restrict__ mx, int numz, GroupGrid g, int64_t ngroups,
     const int64_t *__restrict__ rowmx /*[numz][NHS] byte offsets of the source rows in the plane of maxima*/,
     const uint32_t *__restrict__ rowchg, HarmParams prm, WorkItem *__restrict__ work, unsigned int *__restrict__ ctl,
@@ -1652,6 +1652,201 @@ __global__ __launch_bounds__(256) void k_prefilter(
                     } else { // the global list is full too: the plain sum will run, nothing more to do here
                         ctl[1] = 1u;
                         dead = 1u;
+                    }
+                }
+            }
+        }
+        if ((zi & 7) == 7 && dead)
+            break;
+    }
+    __syncthreads();
+    const unsigned int n = min(ln, (unsigned int) LCAP);
+    if (threadIdx.x == 0 && n)
+        gbase = atomicAdd(&ctl[0], n);
+    __syncthreads();
+    for (unsigned int i = threadIdx.x; i < n; i += 256) {
+        if (gbase + i < work_cap)
+            work[gbase + i] = lst[i];
+        else
+            ctl[1] = 1u;
+    }
+}
+
+// The entries of one source that bound the cells of one group of four fundamental columns (first column cf,
+// last cl): e0 and, if d == 1, the next one.  d > 1: two consecutive entries do not cover them (a source
+// below the plane, or cells spread over three entries).
+__device__ __forceinline__ void source_entries(const GroupGrid &g, uint32_t cf, uint32_t cl, int s, int h, uint32_t &e0, uint32_t &d)
+{
+    const uint32_t s0 = (uint32_t) (((uint64_t) cf * h + (1u << (s - 1))) >> s), s1 = (uint32_t) (((uint64_t) cl * h + (1u << (s - 1))) >> s);
+    e0 = 0;
+    d = 3;
+    if (s0 >= (uint32_t) g.prepop_col0) {
+        e0 = group_entry_of(g, s0);
+        d = group_entry_of(g, s1) - e0;
+    }
+    if (d == 2) { // three entries: fine when the middle one is a block's short group (it stands for six columns)
+        const uint32_t mid = (e0 + 1) % (uint32_t) kGpb;
+        if (g.a == 0 && mid == (uint32_t) kGpb - 1) {
+            e0 += 1;
+            d = 1;
+        } else if (g.a == 2 && mid == 0) {
+            d = 1;
+        }
+    }
+}
+// v_perm_b32 selector that puts entry j0 of four consecutive ones (8 bytes) in the lower half and entry j1 in the upper
+__device__ __forceinline__ uint32_t pair_selector(uint32_t j0, uint32_t j1)
+{
+    return (2u * j0) | ((2u * j0 + 1u) << 8) | ((2u * j1) << 16) | ((2u * j1 + 1u) << 24);
+}
+
+// k_prefilter_lanes is bound by the number of its load instructions (two 16-bit loads per source, lane and
+// move of the source's row), not by bytes.  Here a lane takes two ADJACENT groups (eight columns): their own
+// entries are one aligned 32-bit word, and the entries both need of a source lie within four consecutive
+// ones starting at an even entry -- one 8-byte load at a 4-byte boundary per source and lane, a quarter of
+// the load instructions per group.  A byte permute picks each group's two entries out of the eight bytes.
+template <int NSTAGES>
+__global__ __launch_bounds__(256) void k_prefilter_pairs(
+    const unsigned short *__restrict__ mx, int numz, GroupGrid g, int64_t ngroups,
+    const int64_t *__restrict__ rowmx /*[numz][NHS] byte offsets of the source rows in the plane of maxima*/,
+    const uint32_t *__restrict__ rowchg, HarmParams prm, WorkItem *__restrict__ work, unsigned int *__restrict__ ctl,
+    unsigned int work_cap, int xcd_remap, const unsigned int *__restrict__ flags)
+{
+    constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
+    constexpr int LCAP = 2048;
+    __shared__ WorkItem lst[LCAP];
+    __shared__ unsigned int ln, gbase, dead;
+    const int lane = threadIdx.x & 63;
+    const int64_t npairs = ngroups / 2; // groups per block and hence in all: even
+    unsigned int tile = blockIdx.x;
+    if (xcd_remap) {
+        const unsigned int per = (gridDim.x + 7) / 8;
+        tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+        if ((int64_t) tile * 256 >= npairs)
+            return;
+    }
+    if (flags[0] != 0) { // negative powers in the plane: the bounds do not hold
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            ctl[1] = 1u;
+        return;
+    }
+    if (threadIdx.x == 0) {
+        ln = 0;
+        dead = 0;
+    }
+    __syncthreads();
+    const int64_t pid = (int64_t) tile * 256 + threadIdx.x;
+    const bool live = pid < npairs;
+    const uint32_t gidA = live ? 2u * (uint32_t) pid : 0u; // the first of the lane's two groups
+    const uint32_t sb = gidA / (uint32_t) kGpb;
+    const int lgA = (int) (gidA % (uint32_t) kGpb);
+    uint32_t cf[2], cl[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int lg = lgA + k;
+        const int lfirst = max(4 * lg - g.a, 0), llast = min(4 * lg - g.a + 3, kUseLen - 1);
+        cf[k] = (uint32_t) g.search_col0 + sb * (uint32_t) kUseLen + (uint32_t) lfirst;
+        cl[k] = cf[k] + (uint32_t) (llast - lfirst);
+    }
+    const uint32_t foff = 2u * ((uint32_t) (g.nprepop + sb) * (uint32_t) kGpb + (uint32_t) lgA); // both groups' own entries: a multiple of 4
+    uint32_t off[NHS];    // byte offset in a row of the first of the four entries loaded of source i (a multiple of 4)
+    uint32_t sel[2][NHS]; // per group: the byte permute that picks its two entries out of the four
+    bool force[2] = {false, false}; // a group whose source cells the four entries do not cover: always listed
+    {
+        int i = 0;
+#pragma unroll
+        for (int s = 1; s < NSTAGES; s++)
+#pragma unroll
+            for (int h = 1; h < (1 << s); h += 2) {
+                uint32_t e0[2], d[2];
+                source_entries(g, cf[0], cl[0], s, h, e0[0], d[0]);
+                source_entries(g, cf[1], cl[1], s, h, e0[1], d[1]);
+                const uint32_t eb = (d[0] <= 1 ? e0[0] : d[1] <= 1 ? e0[1] : 0u) & ~1u;
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const uint32_t j0 = e0[k] - eb; // wraps round to a large number below eb
+                    const bool ok = d[k] <= 1 && j0 + d[k] <= 3u;
+                    force[k] = force[k] || !ok;
+                    sel[k][i] = ok ? pair_selector(j0, j0 + d[k]) : 0x03020100u;
+                }
+                off[i++] = 2u * eb;
+                __builtin_amdgcn_sched_barrier(0); // one source after the other: interleaved, the set-up sets the register count
+            }
+    }
+    const unsigned long long live_mask = __ballot(live);
+    const unsigned long long force_mask[2] = {__ballot(force[0]), __ballot(force[1])};
+    const char *mbytes = reinterpret_cast<const char *>(mx);
+    const int64_t rowb = 2 * g.mxlen;
+    uint2 w[NHS];
+    for (int zi = 0; zi < numz; zi++) {
+        const uint32_t fm = *reinterpret_cast<const uint32_t *>(mbytes + (size_t) zi * (size_t) rowb + foff);
+        const uint32_t chg = NH > 0 ? rowchg[zi] : 0u;
+        int64_t ro[NHS];
+#pragma unroll
+        for (int i = 0; i < NH; i++)
+            ro[i] = rowmx[(size_t) zi * NHS + i];
+#pragma unroll
+        for (int i = 0; i < NH; i++)
+            asm volatile("" : "+v"(off[i]));
+#pragma unroll
+        for (int i = 0; i < NH; i++) {
+            if (chg & (1u << i))
+                __builtin_memcpy(&w[i], __builtin_assume_aligned(mbytes + ro[i] + off[i], 4), 8); // one 8-byte load at a 4-byte boundary
+        }
+        unsigned long long crossing[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            // bound_value() of the group's own entry: the word's lower / upper half
+            float p = __uint_as_float(k == 0 ? (fm << 16) + 0x10000u : (fm & 0xffff0000u) + 0x10000u);
+            crossing[k] = force_mask[k];
+            int i = 0;
+#pragma unroll
+            for (int s = 0; s < NSTAGES; s++) {
+                if (s > 0) {
+#pragma unroll
+                    for (int h = 1; h < (1 << s); h += 2) {
+                        const uint32_t two = __builtin_amdgcn_perm(w[i].y, w[i].x, sel[k][i]);
+                        uint32_t m;
+                        asm("v_pk_max_u16 %0, %1, %1 op_sel:[1,0]" : "=v"(m) : "v"(two)); // lower half: the larger of the two entries
+                        p += __uint_as_float((m << 16) + 0x10000u);                       // the upper half's leftovers shift out
+                        i++;
+                    }
+                }
+                crossing[k] |= __ballot(!(p <= prm.powcut[s])); // a NaN (the bound of an infinite power) counts as a crossing
+            }
+            crossing[k] &= live_mask;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const unsigned long long mask = crossing[k];
+            if (mask) { // into the workgroup's list first: one atomic on the global counter per workgroup, not per row
+                const bool any = (mask >> lane) & 1ull;
+                unsigned int base = 0;
+                const int leader = __ffsll((long long) mask) - 1;
+                if (lane == leader)
+                    base = atomicAdd(&ln, (unsigned int) __popcll(mask));
+                base = __shfl(base, leader);
+                const unsigned int pos = base + (unsigned int) __popcll(mask & ((1ull << lane) - 1ull));
+                const WorkItem wi{(uint32_t) zi, 2u * (uint32_t) pid + (uint32_t) k};
+                if (any && pos < LCAP)
+                    lst[pos] = wi;
+                // the workgroup's list is full (a bright signal fills the rows of its columns): the rest of this
+                // wave's row goes straight to the global list, again with one atomic
+                const unsigned long long over = __ballot(any && pos >= LCAP);
+                if (over) {
+                    unsigned int gb = 0;
+                    const int l2 = __ffsll((long long) over) - 1;
+                    if (lane == l2)
+                        gb = atomicAdd(&ctl[0], (unsigned int) __popcll(over));
+                    gb = __shfl(gb, l2);
+                    if (any && pos >= LCAP) {
+                        const unsigned int gpos = gb + (unsigned int) __popcll(over & ((1ull << lane) - 1ull));
+                        if (gpos < work_cap) {
+                            work[gpos] = wi;
+                        } else { // the global list is full too: the plain sum will run, nothing more to do here
+                            ctl[1] = 1u;
+                            dead = 1u;
+                        }
                     }
                 }
             }

@@ -108,6 +108,7 @@ struct Tuning {
     int use_graph = 1;      // small searches: one captured graph per launch instead of nine stream operations
     int hs_bound = 1;       // harmonic sum over 16-bit upper bounds of the plane, exact where a bound crosses
     int pf_list_cap = 0;    // entries of the coarse bound's list of (row, group)s; 0: 1/64 of all of them (tests lower it)
+    int pf_pairs = 1;       // coarse bound: a lane sums two adjacent groups of four columns (1: up to 8 harmonics, 2: 16 too)
                             // (0: off, float plane only; 1: on; 2 / 3: on, one / two columns per lane forced)
 };
 
@@ -774,7 +775,11 @@ int launch_prefilter(accelgpu_ctx *ctx, int nstages, const accelk::HarmParams &p
         ctx->mx_fix_pending = false;
     }
     const int64_t ngroups = (int64_t) ctx->nsearch * accelk::kGpb;
-    unsigned nt = (unsigned) ((ngroups + 255) / 256);
+    // up to 8 harmonics: a lane takes two adjacent groups (k_prefilter_pairs, a quarter of the load instructions:
+    // 0.69 against 0.95 ms on a 2^23-point, zmax 200 plane); with 16 its registers leave five waves per SIMD and it
+    // gains nothing over one group per lane (pf_pairs = 2 runs it there too, 0 never)
+    const bool pairs = (ctx->tune.pf_pairs == 1 && nstages <= 4) || (ctx->tune.pf_pairs == 2 && nstages <= 5);
+    unsigned nt = (unsigned) (((pairs ? ngroups / 2 : ngroups) + 255) / 256);
     if (remap)
         nt = ((nt + 7) / 8) * 8;
     unsigned int wcap = (unsigned int) std::min<size_t>(ctx->work_cap, 0xFFFFFFFFu);
@@ -782,8 +787,12 @@ int launch_prefilter(accelgpu_ctx *ctx, int nstages, const accelk::HarmParams &p
         wcap = std::min(wcap, (unsigned int) ctx->tune.pf_list_cap);
 #define LAUNCH_PF(NS)                                                                                          \
     do {                                                                                                       \
-        hipLaunchKernelGGL((accelk::k_prefilter<NS>), dim3(nt), dim3(256), 0, ctx->stream, ctx->d_mx, ctx->numz, g, ngroups, \
-                           ctx->d_rowmx, ctx->d_rowchg, prm, ctx->d_work, ctx->d_ctl, wcap, remap, ctx->d_flags);           \
+        if (pairs)                                                                                             \
+            hipLaunchKernelGGL((accelk::k_prefilter_pairs<(NS > 5 ? 5 : NS)>), dim3(nt), dim3(256), 0, ctx->stream, ctx->d_mx, ctx->numz, g, \
+                               ngroups, ctx->d_rowmx, ctx->d_rowchg, prm, ctx->d_work, ctx->d_ctl, wcap, remap, ctx->d_flags); \
+        else                                                                                                   \
+            hipLaunchKernelGGL((accelk::k_prefilter_lanes<NS>), dim3(nt), dim3(256), 0, ctx->stream, ctx->d_mx, ctx->numz, g, \
+                               ngroups, ctx->d_rowmx, ctx->d_rowchg, prm, ctx->d_work, ctx->d_ctl, wcap, remap, ctx->d_flags); \
         hipLaunchKernelGGL((accelk::k_flagged_exact<NS>), dim3(4096), dim3(256), 0, ctx->stream, ctx->d_hi, ctx->d_lo,       \
                            ctx->setup.rlen, g, ctx->d_rowhalf, prm, ctx->d_work, ctx->d_ctl, wcap, out.hits, out.count, cap); \
     } while (0)
@@ -1245,6 +1254,7 @@ const TuneName kTuneNames[] = {
     {"std_table", &Tuning::std_table},       {"std_blocks", &Tuning::std_blocks},
     {"opt_nt", &Tuning::opt_nt},             {"use_graph", &Tuning::use_graph},
     {"hs_bound", &Tuning::hs_bound},         {"pf_list_cap", &Tuning::pf_list_cap},
+    {"pf_pairs", &Tuning::pf_pairs},
 };
 
 void tuning_from_env(Tuning *t)

@@ -62,6 +62,30 @@ def test_same_hits_for_every_number_of_harmonics(gpu, numharm, zmax):
     _assert_same(res)
 
 
+@pytest.mark.parametrize("numharm", [2, 4, 8, 16])
+@pytest.mark.parametrize("zmax", [0, 50])
+def test_coarse_bound_one_or_two_groups_per_lane(gpu, numharm, zmax):
+    """The coarse bound's two kernels (a lane sums one group of four columns with two 16-bit loads per source,
+    or two adjacent groups with one 8-byte load; pf_pairs picks) list different (row, group)s where a source's
+    entries fall outside the loaded ones, and must end in the same hits as the float-plane sum."""
+    N, dt = 1 << 20, 1e-4
+    fft = synth.make_fft(N, dt, [dict(f=223.456, z=5.0, amp=0.3, duty=0.08), dict(f=1741.0, z=-19.0, amp=0.2, duty=0.05)],
+                         seed=400 + numharm)
+    gpu.configure(N // 2, N, dt, zmax, numharm, sigma=1.5, flo=11.0, fhi=4900.0)
+    gpu.load_fft(fft)
+    try:
+        res = _hits_by_mode(gpu, modes=(0,))
+        for pairs in (0, 1, 2):
+            gpu.set_tuning("pf_pairs", pairs)
+            res[10 + pairs] = _hits_by_mode(gpu, modes=(4,))[4]
+            assert gpu.get_tuning("hs_prefilter_active") == 1 and gpu.get_tuning("pf_listed") > 0
+    finally:
+        gpu.set_tuning("pf_pairs", 1)
+    assert len(res[0]) > 50
+    for m, h in res.items():
+        assert h.tobytes() == res[0].tobytes(), "pf_pairs=%d differs from the float-plane sum" % (m - 10)
+
+
 @pytest.mark.parametrize("numharm", [8, 32])
 def test_ragged_end_and_odd_geometry(gpu, numharm):
     """A search whose column count is not a multiple of the kernels' tiles (dead lanes in the
