@@ -125,7 +125,8 @@ int accelgpu_synchronize(accelgpu_ctx *ctx);
  *   pf_list_cap    0   capacity of that list in entries (0: 1/64 of all there are)
  *   pf_pairs       1   with up to 8 harmonics the coarse bound's kernel gives a lane two adjacent
  *                      groups of four columns (one 8-byte load per source and lane instead of four
- *                      16-bit loads); 2: with 16 harmonics too; 0: never
+ *                      16-bit loads); 2: with 16 harmonics too; 3: the 8-byte loads with one group
+ *                      per lane; 0: never
  *   hits_cap   2^20    records in each device hit buffer (set: reallocates both; they
  *                      grow on their own when a search overflows them)
  * ref: none (the reference's only run-time knob is -ncpus). */

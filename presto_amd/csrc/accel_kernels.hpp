@@ -1701,11 +1701,11 @@ __device__ __forceinline__ uint32_t pair_selector(uint32_t j0, uint32_t j1)
 }
 
 // k_prefilter_lanes is bound by the number of its load instructions (two 16-bit loads per source, lane and
-// move of the source's row), not by bytes.  Here a lane takes two ADJACENT groups (eight columns): their own
-// entries are one aligned 32-bit word, and the entries both need of a source lie within four consecutive
-// ones starting at an even entry -- one 8-byte load at a 4-byte boundary per source and lane, a quarter of
-// the load instructions per group.  A byte permute picks each group's two entries out of the eight bytes.
-template <int NSTAGES>
+// move of the source's row), not by bytes.  Here a group's two entries of a source come out of ONE 8-byte load
+// at a 4-byte boundary: four consecutive entries from an even one; a byte permute picks the two.  NG = 2: a
+// lane takes two ADJACENT groups (eight columns): their own entries are one aligned 32-bit word, and the
+// entries both need of a source lie within the same four -- a quarter of the load instructions per group.
+template <int NSTAGES, int NG>
 __global__ __launch_bounds__(256) void k_prefilter_pairs(
     const unsigned short *__restrict__ mx, int numz, GroupGrid g, int64_t ngroups,
     const int64_t *__restrict__ rowmx /*[numz][NHS] byte offsets of the source rows in the plane of maxima*/,
@@ -1717,7 +1717,7 @@ __global__ __launch_bounds__(256) void k_prefilter_pairs(
     __shared__ WorkItem lst[LCAP];
     __shared__ unsigned int ln, gbase, dead;
     const int lane = threadIdx.x & 63;
-    const int64_t npairs = ngroups / 2; // groups per block and hence in all: even
+    const int64_t npairs = ngroups / NG; // lanes wanted (groups per block and hence in all: even)
     unsigned int tile = blockIdx.x;
     if (xcd_remap) {
         const unsigned int per = (gridDim.x + 7) / 8;
@@ -1737,33 +1737,34 @@ __global__ __launch_bounds__(256) void k_prefilter_pairs(
     __syncthreads();
     const int64_t pid = (int64_t) tile * 256 + threadIdx.x;
     const bool live = pid < npairs;
-    const uint32_t gidA = live ? 2u * (uint32_t) pid : 0u; // the first of the lane's two groups
+    const uint32_t gidA = live ? (uint32_t) NG * (uint32_t) pid : 0u; // the first of the lane's groups
     const uint32_t sb = gidA / (uint32_t) kGpb;
     const int lgA = (int) (gidA % (uint32_t) kGpb);
-    uint32_t cf[2], cl[2];
+    uint32_t cf[NG], cl[NG];
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < NG; k++) {
         const int lg = lgA + k;
         const int lfirst = max(4 * lg - g.a, 0), llast = min(4 * lg - g.a + 3, kUseLen - 1);
         cf[k] = (uint32_t) g.search_col0 + sb * (uint32_t) kUseLen + (uint32_t) lfirst;
         cl[k] = cf[k] + (uint32_t) (llast - lfirst);
     }
-    const uint32_t foff = 2u * ((uint32_t) (g.nprepop + sb) * (uint32_t) kGpb + (uint32_t) lgA); // both groups' own entries: a multiple of 4
+    const uint32_t foff = 2u * ((uint32_t) (g.nprepop + sb) * (uint32_t) kGpb + (uint32_t) lgA); // the groups' own entries (two: a multiple of 4)
     uint32_t off[NHS];    // byte offset in a row of the first of the four entries loaded of source i (a multiple of 4)
-    uint32_t sel[2][NHS]; // per group: the byte permute that picks its two entries out of the four
-    bool force[2] = {false, false}; // a group whose source cells the four entries do not cover: always listed
+    uint32_t sel[NG][NHS]; // per group: the byte permute that picks its two entries out of the four
+    bool force[NG] = {}; // a group whose source cells the four entries do not cover: always listed
     {
         int i = 0;
 #pragma unroll
         for (int s = 1; s < NSTAGES; s++)
 #pragma unroll
             for (int h = 1; h < (1 << s); h += 2) {
-                uint32_t e0[2], d[2];
-                source_entries(g, cf[0], cl[0], s, h, e0[0], d[0]);
-                source_entries(g, cf[1], cl[1], s, h, e0[1], d[1]);
-                const uint32_t eb = (d[0] <= 1 ? e0[0] : d[1] <= 1 ? e0[1] : 0u) & ~1u;
+                uint32_t e0[NG], d[NG];
 #pragma unroll
-                for (int k = 0; k < 2; k++) {
+                for (int k = 0; k < NG; k++)
+                    source_entries(g, cf[k], cl[k], s, h, e0[k], d[k]);
+                const uint32_t eb = (d[0] <= 1 ? e0[0] : d[NG - 1] <= 1 ? e0[NG - 1] : 0u) & ~1u;
+#pragma unroll
+                for (int k = 0; k < NG; k++) {
                     const uint32_t j0 = e0[k] - eb; // wraps round to a large number below eb
                     const bool ok = d[k] <= 1 && j0 + d[k] <= 3u;
                     force[k] = force[k] || !ok;
@@ -1774,12 +1775,16 @@ __global__ __launch_bounds__(256) void k_prefilter_pairs(
             }
     }
     const unsigned long long live_mask = __ballot(live);
-    const unsigned long long force_mask[2] = {__ballot(force[0]), __ballot(force[1])};
+    unsigned long long force_mask[NG];
+#pragma unroll
+    for (int k = 0; k < NG; k++)
+        force_mask[k] = __ballot(force[k]);
     const char *mbytes = reinterpret_cast<const char *>(mx);
     const int64_t rowb = 2 * g.mxlen;
     uint2 w[NHS];
     for (int zi = 0; zi < numz; zi++) {
-        const uint32_t fm = *reinterpret_cast<const uint32_t *>(mbytes + (size_t) zi * (size_t) rowb + foff);
+        const char *own = mbytes + (size_t) zi * (size_t) rowb + foff;
+        const uint32_t fm = NG == 2 ? *reinterpret_cast<const uint32_t *>(own) : (uint32_t) *reinterpret_cast<const unsigned short *>(own);
         const uint32_t chg = NH > 0 ? rowchg[zi] : 0u;
         int64_t ro[NHS];
 #pragma unroll
@@ -1793,9 +1798,9 @@ __global__ __launch_bounds__(256) void k_prefilter_pairs(
             if (chg & (1u << i))
                 __builtin_memcpy(&w[i], __builtin_assume_aligned(mbytes + ro[i] + off[i], 4), 8); // one 8-byte load at a 4-byte boundary
         }
-        unsigned long long crossing[2];
+        unsigned long long crossing[NG];
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < NG; k++) {
             // bound_value() of the group's own entry: the word's lower / upper half
             float p = __uint_as_float(k == 0 ? (fm << 16) + 0x10000u : (fm & 0xffff0000u) + 0x10000u);
             crossing[k] = force_mask[k];
@@ -1817,7 +1822,7 @@ __global__ __launch_bounds__(256) void k_prefilter_pairs(
             crossing[k] &= live_mask;
         }
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < NG; k++) {
             const unsigned long long mask = crossing[k];
             if (mask) { // into the workgroup's list first: one atomic on the global counter per workgroup, not per row
                 const bool any = (mask >> lane) & 1ull;
@@ -1827,7 +1832,7 @@ __global__ __launch_bounds__(256) void k_prefilter_pairs(
                     base = atomicAdd(&ln, (unsigned int) __popcll(mask));
                 base = __shfl(base, leader);
                 const unsigned int pos = base + (unsigned int) __popcll(mask & ((1ull << lane) - 1ull));
-                const WorkItem wi{(uint32_t) zi, 2u * (uint32_t) pid + (uint32_t) k};
+                const WorkItem wi{(uint32_t) zi, (uint32_t) NG * (uint32_t) pid + (uint32_t) k};
                 if (any && pos < LCAP)
                     lst[pos] = wi;
                 // the workgroup's list is full (a bright signal fills the rows of its columns): the rest of this

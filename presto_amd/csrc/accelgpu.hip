@@ -108,7 +108,8 @@ struct Tuning {
     int use_graph = 1;      // small searches: one captured graph per launch instead of nine stream operations
     int hs_bound = 1;       // harmonic sum over 16-bit upper bounds of the plane, exact where a bound crosses
     int pf_list_cap = 0;    // entries of the coarse bound's list of (row, group)s; 0: 1/64 of all of them (tests lower it)
-    int pf_pairs = 1;       // coarse bound: a lane sums two adjacent groups of four columns (1: up to 8 harmonics, 2: 16 too)
+    int pf_pairs = 1;       // coarse bound from 8-byte loads: 1 two adjacent groups per lane up to 8 harmonics, 2: with 16 too,
+                            // 3: one group per lane, 0: never
                             // (0: off, float plane only; 1: on; 2 / 3: on, one / two columns per lane forced)
 };
 
@@ -775,11 +776,14 @@ int launch_prefilter(accelgpu_ctx *ctx, int nstages, const accelk::HarmParams &p
         ctx->mx_fix_pending = false;
     }
     const int64_t ngroups = (int64_t) ctx->nsearch * accelk::kGpb;
-    // up to 8 harmonics: a lane takes two adjacent groups (k_prefilter_pairs, a quarter of the load instructions:
-    // 0.69 against 0.95 ms on a 2^23-point, zmax 200 plane); with 16 its registers leave five waves per SIMD and it
-    // gains nothing over one group per lane (pf_pairs = 2 runs it there too, 0 never)
-    const bool pairs = (ctx->tune.pf_pairs == 1 && nstages <= 4) || (ctx->tune.pf_pairs == 2 && nstages <= 5);
-    unsigned nt = (unsigned) (((pairs ? ngroups / 2 : ngroups) + 255) / 256);
+    // One 8-byte load per source (k_prefilter_pairs): with up to 8 harmonics a lane takes two adjacent groups (a
+    // quarter of the load instructions: 0.69 against 0.95 ms on a 2^23-point, zmax 200 plane).  With 16 harmonics
+    // its registers leave five waves per SIMD: 1.71 ms with two groups per lane, 2.28 with one, against 1.72 ms
+    // for two 16-bit loads per source (k_prefilter_lanes), which lists fewer groups and stays.  pf_pairs: 0 never,
+    // 2 two groups per lane with 16 harmonics too, 3 one group per lane.
+    const int pp = ctx->tune.pf_pairs;
+    const int per_lane = nstages > 5 || pp == 0 ? 0 : pp == 3 ? 1 : pp == 2 ? 2 : nstages <= 4 ? 2 : 0;
+    unsigned nt = (unsigned) ((ngroups / std::max(per_lane, 1) + 255) / 256);
     if (remap)
         nt = ((nt + 7) / 8) * 8;
     unsigned int wcap = (unsigned int) std::min<size_t>(ctx->work_cap, 0xFFFFFFFFu);
@@ -787,8 +791,11 @@ int launch_prefilter(accelgpu_ctx *ctx, int nstages, const accelk::HarmParams &p
         wcap = std::min(wcap, (unsigned int) ctx->tune.pf_list_cap);
 #define LAUNCH_PF(NS)                                                                                          \
     do {                                                                                                       \
-        if (pairs)                                                                                             \
-            hipLaunchKernelGGL((accelk::k_prefilter_pairs<(NS > 5 ? 5 : NS)>), dim3(nt), dim3(256), 0, ctx->stream, ctx->d_mx, ctx->numz, g, \
+        if (per_lane == 2)                                                                                     \
+            hipLaunchKernelGGL((accelk::k_prefilter_pairs<(NS > 5 ? 5 : NS), 2>), dim3(nt), dim3(256), 0, ctx->stream, ctx->d_mx, ctx->numz, g, \
+                               ngroups, ctx->d_rowmx, ctx->d_rowchg, prm, ctx->d_work, ctx->d_ctl, wcap, remap, ctx->d_flags); \
+        else if (per_lane == 1)                                                                                \
+            hipLaunchKernelGGL((accelk::k_prefilter_pairs<(NS > 5 ? 5 : NS), 1>), dim3(nt), dim3(256), 0, ctx->stream, ctx->d_mx, ctx->numz, g, \
                                ngroups, ctx->d_rowmx, ctx->d_rowchg, prm, ctx->d_work, ctx->d_ctl, wcap, remap, ctx->d_flags); \
         else                                                                                                   \
             hipLaunchKernelGGL((accelk::k_prefilter_lanes<NS>), dim3(nt), dim3(256), 0, ctx->stream, ctx->d_mx, ctx->numz, g, \

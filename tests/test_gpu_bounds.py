@@ -75,7 +75,7 @@ def test_coarse_bound_one_or_two_groups_per_lane(gpu, numharm, zmax):
     gpu.load_fft(fft)
     try:
         res = _hits_by_mode(gpu, modes=(0,))
-        for pairs in (0, 1, 2):
+        for pairs in (0, 1, 2, 3):
             gpu.set_tuning("pf_pairs", pairs)
             res[10 + pairs] = _hits_by_mode(gpu, modes=(4,))[4]
             assert gpu.get_tuning("hs_prefilter_active") == 1 and gpu.get_tuning("pf_listed") > 0
