@@ -268,7 +268,7 @@ def main():
             if pmc.get("prefilter", False) != prefilter or pmc.get("bounded", False) != bounded:
                 pmc = {}
         src = "profiles/pmc_kernels.json (rocprofv3 --pmc passes of this command, not this run)" if pmc else None
-        hs_name = ("k_prefilter + k_flagged_exact <%d stages> over the maxima of four columns' upper halves" if prefilter
+        hs_name = ("k_prefilter_lanes / _pairs + k_flagged_exact <%d stages> over the maxima of four columns' upper halves" if prefilter
                    else "k_harmsum_bw<%d stages> over 16-bit upper halves of the plane" if bounded
                    else "k_harmsum<%d stages>") % setup.numharmstages
         roof_hs = {"kernel": hs_name, "bound": "hbm", "achieved": hs_alg / (hs_ms * 1e-3) / 1e9 if hs_ms > 0 else 0.0,
