@@ -113,13 +113,15 @@ def test_cfg4_full_size(gpu):
     assert setup.num_search_blocks == 17965 and setup.plane_bytes > 161e9
 
 
-def _oracle_parity(gpu, oracle, name, N, max_hits):
+def _oracle_parity(gpu, oracle, name, N, max_hits, numharm=None, min_hits=1000):
     """The whole search on the GPU against the whole search on the CPU oracle, same
     spectrum, same flags: the main loop of src/accelsearch.c:165-218 with
     search_ffdotpows (src/accel_utils.c:1259-1299) at every stage."""
     import os
     from oracle.compare import assert_same_search
     fft, c = synth.config_fft(name, N=N)
+    if numharm is not None:
+        c = dict(c, numharm=numharm)
     threads = min(16, os.cpu_count() or 1)
     s = oracle.Search(fft, N, c["dt"], c["zmax"], c["numharm"], fhi=1e9, nthreads=threads)
     want_hits, want_cands = s.run(max_hits=max_hits)
@@ -127,7 +129,7 @@ def _oracle_parity(gpu, oracle, name, N, max_hits):
     setup = gpu.configure(fft.size, N, c["dt"], c["zmax"], c["numharm"], fhi=1e9)
     gpu.load_fft(fft)
     got_hits, got_cands, sig, added = gpu.search(max_hits=max_hits)
-    assert len(want_hits) > 1000
+    assert len(want_hits) > min_hits
     rel, edge_g, edge_w = assert_same_search(setup.powcut, got_hits, want_hits, min_matched=0.995)
     if len(edge_g) == 0 and len(edge_w) == 0:
         assert np.array_equal(got_cands["r"], want_cands["r"])
@@ -151,6 +153,14 @@ def test_cfg2_full_size_against_oracle(gpu, oracle):
     """The headline workload itself (2^23-point series, zmax 200, numharm 16)."""
     matched, only_g, only_w = _oracle_parity(gpu, oracle, "cfg2", 1 << 23, 8_000_000)
     print("cfg2 2^23: %d hits matched, %d GPU-only, %d oracle-only at a threshold" % (matched, only_g, only_w))
+
+
+def test_cfg2_full_size_eight_harmonics_against_oracle(gpu, oracle):
+    """The headline plane searched with accelsearch's default of 8 harmonics: the coarse bound then runs
+    its two-groups-per-lane kernel (k_prefilter_pairs), which planes of this size alone select."""
+    matched, only_g, only_w = _oracle_parity(gpu, oracle, "cfg2", 1 << 23, 8_000_000, numharm=8, min_hits=100)
+    assert gpu.get_tuning("hs_prefilter_active") == 1 and gpu.get_tuning("pf_pairs") == 1
+    print("cfg2 2^23, 8 harmonics: %d hits matched, %d GPU-only, %d oracle-only at a threshold" % (matched, only_g, only_w))
 
 
 def test_cfg5_reduced_against_oracle(gpu, oracle):
