@@ -110,7 +110,7 @@ int accelgpu_synchronize(accelgpu_ctx *ctx);
  *   hs_bound       1   the in-memory plane is kept as two planes of 16-bit halves of every power's
  *                      float and the harmonic sum reads the upper halves alone, as upper bounds,
  *                      fetching the lower halves wherever a bound sum crosses a threshold: the
- *                      same hits from half the bytes.  On large planes searched with 8 or 16
+ *                      same hits from half the bytes.  On large planes searched with 2 to 16
  *                      harmonics (8192-point transforms) a coarser bound runs in front: plane
  *                      generation also writes the largest upper half of every four columns, the
  *                      sums of those single out the few (row, four columns) that could cross a
