@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 SUMF2 = {1: 0.0, 2: 0.25, 4: 0.875, 8: 2.1875, 16: 4.84375, 32: 10.171875}
 HBM_PEAK_GBS = 8000.0
+FP32_VECTOR_PEAK_TFLOPS = 157.3
 
 
 def cpu_baseline(cfg, threads):
@@ -138,11 +139,16 @@ def main():
     g.timings(reset=True)
     barrier()
     t0 = time.perf_counter()
+    cpu0 = time.process_time()                 # all threads of this process
     results = run_steps(args.steps)
     if multi:
         merged = merge(results)
     barrier()
     elapsed = time.perf_counter() - t0
+    host_cpu_s = time.process_time() - cpu0
+    listed = g.get_tuning("pf_last_listed")    # of the last collected trial: (row, four columns) the coarse bound listed
+    bounded = g.get_tuning("hs_bound_active") == 1
+    prefilter = bounded and listed != -2       # the coarse bound ran in front of the harmonic sum
     if multi:
         te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -237,6 +243,30 @@ def main():
         n_opt /= float(kf)
         g.set_profiling(True)
 
+    # The same spectra with every threshold lowered to 0.85 of its value (reported beside): the coarse bound in
+    # front of the harmonic sum would then list 2 % of its (row, four columns) instead of 0.08 %, which costs more
+    # than it saves; a sample taken before the walk says so, the bounded sum runs over the whole plane instead,
+    # and the context leaves the coarse bound out of its next trials.  (-sigma goes down to 1, spectra carry
+    # interference: the rate must not fall off a cliff there.)
+    dense_rate = dense_hits = None
+    if rank == 0 and not args.timed_only:
+        from presto_amd.api import plan
+        dense = plan(numbins, cfg["N"], cfg["dt"], cfg["zmax"], cfg["numharm"], fhi=1e9)
+        for st in range(dense.numharmstages):
+            dense.powcut[st] *= 0.85
+        g.set_search(dense)
+        saved_setup, setup = setup, dense
+        run_steps(3)
+        kd = max(8, min(args.steps, 20))
+        g.synchronize()
+        t1 = time.perf_counter()
+        dres = run_steps(kd)
+        g.synchronize()
+        dense_rate = kd / (time.perf_counter() - t1)
+        dense_hits = float(np.mean([r[0] for r in dres]))
+        setup = saved_setup
+        g.set_search(setup)
+
     if rank == 0:
         cells = setup.numz * 7470 * setup.num_search_blocks
         nblk = setup.num_search_blocks + setup.num_prepop_blocks
@@ -245,19 +275,18 @@ def main():
         # float plane.  The kernels here read the plane's 16-bit upper halves (2 B per value), and with
         # the coarse bound in front (the largest upper half of every four columns) a quarter of those;
         # both halves only where a bound crosses a threshold.
-        bounded = g.get_tuning("hs_bound_active") == 1
-        prefilter = bounded and g.get_tuning("hs_prefilter_active") == 1
         float_bytes = 4.0 * (1.0 + SUMF2[cfg["numharm"]]) * cells
         hs_alg = float_bytes / 8 if prefilter else float_bytes / 2 if bounded else float_bytes
         hs = tm["harmsum"]
         hs_ms = hs["total_ms"] / max(hs["launches"], 1)
         co = tm["correlate"]
         co_ms = co["total_ms"] / max(co["launches"], 1)
-        # plane generation: the plane has to be stored (4 B per cell of every block), with the group maxima
-        # beside it (2 B per four cells), and the spectrum and the template bank have to be read once
+        # plane generation: the plane has to be stored (4 B per cell of every block) and the spectrum and the
+        # template bank have to be read once; the group maxima it writes beside the plane for the coarse bound
+        # (2 B per four cells) are this design's own overhead, not work the reference's formulation asks for
         L = setup.fftlen
-        co_alg = (4.0 * setup.numz * 7470 * nblk + (2.0 * setup.numz * 1868 * nblk if prefilter else 0.0)
-                  + 8.0 * numbins + 8.0 * setup.numz * L)
+        co_alg = 4.0 * setup.numz * 7470 * nblk + 8.0 * numbins + 8.0 * setup.numz * L
+        co_overhead = 2.0 * setup.numz * 1868 * nblk if prefilter else 0.0
         co_flop = nblk * setup.numz * (5.0 * L * np.log2(L) + 6.0 * L + 3.0 * 7470)
         pmc = {}
         pmc_path = os.path.join(ROOT, "profiles", "pmc_kernels.json")
@@ -280,15 +309,24 @@ def main():
                    "float_plane_bytes_per_launch": float_bytes,
                    "float_plane_equivalent_GBps": float_bytes / (hs_ms * 1e-3) / 1e9 if hs_ms > 0 else 0.0}
         roof_hs["frac"] = roof_hs["achieved"] / HBM_PEAK_GBS
+        if prefilter:
+            # what the coarse bound's time depends on: the share of its (row, four columns) that it had to list for
+            # exact sums (-1: its list was of no use and the bounded sum ran over the whole plane)
+            groups = float(setup.numz) * setup.num_search_blocks * 1868
+            roof_hs["listed"] = listed
+            roof_hs["listed_fraction"] = listed / groups if listed >= 0 else None
+        # Plane generation is FFT arithmetic on the vector ALUs (no matrix product in it, so no MFMA): what binds it is
+        # fp32 vector instruction issue, and it is priced against the 157.3 TFLOP/s fp32 vector peak.  Its compulsory
+        # bytes against the HBM peak are reported beside (they come to the same fraction on this workload).
+        co_tflops = co_flop / (co_ms * 1e-3) / 1e12 if co_ms > 0 else 0.0
         roof_co = {"kernel": "k_correlate_rr (plane generation: %d inverse transforms of %d points)" % (nblk * setup.numz, L),
-                   "bound": "hbm", "achieved": co_alg / (co_ms * 1e-3) / 1e9 if co_ms > 0 else 0.0,
-                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "bound": "fp32-vector", "achieved": co_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                   "frac": co_tflops / FP32_VECTOR_PEAK_TFLOPS,
+                   "flop_per_launch": co_flop, "avg_launch_ms": co_ms,
                    "traffic": pmc.get("correlate_hbm_bytes_per_launch"), "traffic_source": src,
-                   "algorithmic_bytes_per_launch": co_alg, "avg_launch_ms": co_ms,
-                   # not a matrix product: fp32 vector arithmetic against the 157.3 TFLOP/s vector peak
-                   "flop_per_launch": co_flop, "tflops": co_flop / (co_ms * 1e-3) / 1e12 if co_ms > 0 else 0.0,
-                   "frac_of_fp32_vector_peak": co_flop / (co_ms * 1e-3) / 1e12 / 157.3 if co_ms > 0 else 0.0}
-        roof_co["frac"] = roof_co["achieved"] / HBM_PEAK_GBS
+                   "algorithmic_bytes_per_launch": co_alg, "overhead_bytes_per_launch": co_overhead,
+                   "hbm_GBps_on_algorithmic_bytes": co_alg / (co_ms * 1e-3) / 1e9 if co_ms > 0 else 0.0,
+                   "frac_of_hbm_peak": co_alg / (co_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if co_ms > 0 else 0.0}
         # `roofline` describes the kernel that takes most of the step; the other one is reported beside it
         dominant, other = (roof_co, roof_hs) if co_ms >= hs_ms else (roof_hs, roof_co)
         line = {
@@ -312,9 +350,15 @@ def main():
             "cands_per_trial": float(np.mean([len(r[1]) for r in results])),
             "pcie_inclusive_searches_per_s": pcie_rate,
             "pcie_inclusive_pageable_searches_per_s": pcie_pageable_rate,
+            "dense_spectrum_searches_per_s": dense_rate,
+            "dense_spectrum_hits_per_trial": dense_hits,
             "with_optimization_searches_per_s": full_rate,
             "optimize_ms_per_trial": opt_ms,
             "cands_optimized_per_trial": n_opt,
+            # what a rank asks of its host: CPU seconds of all its threads per trial of the timed region (launches,
+            # ordering the hits, sigma per hit on up to 8 threads when a trial has thousands, the list replay)
+            "host_cpu_s_per_trial": host_cpu_s / max(args.steps, 1),
+            "host_threads": {"main": 1, "sigma_workers_max": 7},
         }
         if world == 1 and not args.no_cpu and not args.timed_only:
             threads = min(16, os.cpu_count() or 1)

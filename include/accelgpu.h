@@ -123,6 +123,15 @@ int accelgpu_synchronize(accelgpu_ctx *ctx);
  *                      runs), "pf_listed" ((row, four columns) the last search had to sum
  *                      exactly; -1: too many, the bounded sum ran over the whole plane instead)
  *   pf_list_cap    0   capacity of that list in entries (0: 1/64 of all there are)
+ *   pf_limit_ppm 10000 entries per million (row, four columns) beyond which the list costs more than the
+ *                      bounded sum over the whole plane it replaces; pf_sample 1: a sample of 2^17
+ *                      (row, four columns) is asked before the walk (20 microseconds), and a list
+ *                      that would be longer is not started; pf_memory 1: a context whose list was
+ *                      given up leaves the coarse bound out of its next 4 launches (8, 16 ... 64 when
+ *                      the one after gives up again).  Read-only: "pf_last_listed" (the last
+ *                      COLLECTED launch: entries listed, -1 given up, -2 the coarse bound did not
+ *                      run), "pf_skip" (launches still to go without it).  hs_bound 4 ignores the
+ *                      limit and the memory.
  *   pf_pairs       1   with up to 8 harmonics the coarse bound's kernel gives a lane two adjacent
  *                      groups of four columns (one 8-byte load per source and lane instead of four
  *                      16-bit loads); 2: with 16 harmonics too; 3: the 8-byte loads with one group
@@ -134,6 +143,13 @@ int accelgpu_set_tuning(accelgpu_ctx *ctx, const char *name, int value);
 int accelgpu_get_tuning(accelgpu_ctx *ctx, const char *name, int *value);
 
 /* ---- host-side scalar helpers (no GPU needed) --------------------------- */
+/* Can the coarse bound in front of the harmonic sum run on a search of this shape (tuning knobs aside)?
+ * numharmstages 2..5 unless `forced` (hs_bound = 4: 2..6), at least 2^22 search columns unless forced,
+ * and a plane row of fewer than 2^32 columns in any case: its kernels count columns, groups and list
+ * entries in 32 bits (the sums proper index in 64).  The kernels' workgroup-to-XCD mappings assume the
+ * 8 XCDs of an MI355X.
+ * ref: none (a device-side strategy; the reference's scan is src/accel_utils.c:1259-1299). */
+int accelgpu_coarse_bound_applies(int numharmstages, int64_t search_columns, int64_t rlen, int fftlen, int forced);
 /* ref: z_resp_halfwidth(z, LOWACC), src/responses.c:29-65 */
 int accelgpu_z_resp_halfwidth(double z);
 /* ref: calc_fftlen(), src/accel_utils.c:119-132 */

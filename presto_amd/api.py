@@ -70,6 +70,7 @@ def load_library():
     L.accelgpu_synchronize.argtypes = [vp]
     L.accelgpu_z_resp_halfwidth.argtypes = [d]
     L.accelgpu_calc_fftlen.argtypes = [i, i, i]
+    L.accelgpu_coarse_bound_applies.argtypes = [i, i64, i64, i, i]
     L.accelgpu_candidate_sigma.argtypes = [d, i, d]; L.accelgpu_candidate_sigma.restype = d
     L.accelgpu_power_for_sigma.argtypes = [d, i, d]; L.accelgpu_power_for_sigma.restype = d
     L.accelgpu_plan.argtypes = [i64, i64, d, i, i, d, d, d, i64, pS]

@@ -947,6 +947,10 @@ __global__ __launch_bounds__(256) void k_harmsum(
 // Negative powers do not come out of plane generation; a host can write them into the plane
 // (k_split_span sets flags[0] when it sees one), and then every row takes the exact path.
 // ---------------------------------------------------------------------------
+// The control words of the coarse bound in front of these sums (k_prefilter_*): word kPfFlag set = its list is of
+// no use and the sum over the whole plane has to run.
+constexpr int kPfCtlWords = 48;
+constexpr int kPfFlag = 16;
 constexpr int harm_stage_of(int i) // i-th sub-harmonic in summing order -> its stage s
 {
     int s = 1;
@@ -976,7 +980,7 @@ __global__ __launch_bounds__(256) void k_split_span(const float *__restrict__ sr
     const uint32_t b = __float_as_uint(p);
     hi[r * rlen + i] = (unsigned short) (b >> 16);
     lo[r * rlen + i] = (unsigned short) b;
-    if (p < 0.f)
+    if (b >> 31)       // (the sign bit, so that -0.0 counts: as a 16-bit number its upper half beats every positive one)
         flags[0] = 1u; // the bounds of k_harmsum_b hold for p >= 0 only
 }
 __global__ __launch_bounds__(256) void k_join_span(float *__restrict__ dst, int64_t dst_stride,
@@ -996,7 +1000,7 @@ __global__ __launch_bounds__(256) void k_harmsum_b(
     HarmParams prm, DevHit *__restrict__ hits, unsigned int *__restrict__ count, unsigned int max_hits,
     int xcd_remap, const unsigned int *__restrict__ flags, const unsigned int *__restrict__ gate)
 {
-    if (gate && gate[1] == 0)
+    if (gate && gate[kPfFlag] == 0)
         return; // the listed cells were summed instead
     constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
     const int lane = threadIdx.x & 63;
@@ -1122,7 +1126,7 @@ __global__ __launch_bounds__(256) void k_harmsum_bw(
     HarmParams prm, DevHit *__restrict__ hits, unsigned int *__restrict__ count, unsigned int max_hits,
     int xcd_remap, const unsigned int *__restrict__ flags, const unsigned int *__restrict__ gate)
 {
-    if (gate && gate[1] == 0)
+    if (gate && gate[kPfFlag] == 0)
         return; // the listed cells were summed instead
     constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
     constexpr int TILE = 256 * NC;
@@ -1274,7 +1278,7 @@ __global__ __launch_bounds__(256) void k_harmsum_bl(
     HarmParams prm, DevHit *__restrict__ hits, unsigned int *__restrict__ count, unsigned int max_hits,
     int xcd_remap, const unsigned int *__restrict__ flags, const unsigned int *__restrict__ gate)
 {
-    if (gate && gate[1] == 0)
+    if (gate && gate[kPfFlag] == 0)
         return; // the listed cells were summed instead
     constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
     static_assert(NH >= 1 && NH <= 32 && NSTAGES <= 6, "one lane and one mask bit per source");
@@ -1472,8 +1476,9 @@ __global__ __launch_bounds__(256) void k_group_max(const unsigned short *__restr
                                                    const int64_t *__restrict__ blk_col, const int *__restrict__ blk_ncols,
                                                    GroupGrid g, unsigned short *__restrict__ mx)
 {
-    const int lg = blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y, zi = blockIdx.z;
+    constexpr unsigned int per_block = (kGpb + 255) / 256;
+    const int lg = (int) (blockIdx.x % per_block) * 256 + threadIdx.x;
+    const int b = (int) (blockIdx.x / per_block), zi = blockIdx.z;
     const unsigned short *cells = hi + (size_t) zi * (size_t) rlen + blk_col[b];
     const int ncols = min(blk_ncols[b], kUseLen);
     const bool in = lg < kGpb;
@@ -1514,37 +1519,126 @@ struct WorkItem {
     uint32_t zi;
     uint32_t group; // index of the group of four fundamental columns within the search region
 };
-// work[0..]: the list; ctl[0] = entries wanted (may exceed the capacity), ctl[1] = 1 when the list
-// is of no use (capacity exceeded, or negative powers in the plane) and the plain sum has to run
+// work[0..]: the list.  ctl is kPfCtlWords 32-bit words, zeroed before every launch: ctl[0] = entries wanted in
+// the list so far; ctl[kPfFlag], on a cache line of its own: 1 when the list is of no use (more entries than
+// `limit`, or negative powers in the plane) and the plain sum has to run; ctl[32..33], on another line, one
+// 64-bit word of k_prefilter_sample: bits 0..39 its samples that would be listed, bits 40..63 its workgroups
+// that have finished.
+//
+// The list pays only while it is short: every entry costs four exact column sums, and a walk that ends
+// in a list of no use has cost its whole time for nothing.  Looking while walking is what does not work:
+// operations on one cache line that is being written are served one after the other, about 45 ns each (a
+// returning atomic per workgroup every 16 rows added 0.9 ms to a 1.7 ms walk, a poll by every wave 10 ms);
+// any way out of the row loop, even a changed loop bound, costs the kernels 10 to 30 registers and with them
+// resident workgroups; and cutting the walk into shorter workgroups that report as they end multiplies a
+// fixed cost per workgroup that is a third of the whole (4, 8, 16 row chunks: 3.4, 5.7, 8.9 ms).  So the
+// question is asked BEFORE the walk: k_prefilter_sample works out the bound sums of a few hundred thousand
+// (row, group)s spread evenly over the plane (one per lane: 20 microseconds), its last workgroup scales the
+// count to the whole plane and raises the flag if the list would be longer than `limit`, and the walk's
+// workgroups look at the flag when they begin.
+constexpr int kPfLcap = 2048; // entries of a workgroup's own list in LDS
+struct PfShared {
+    WorkItem lst[kPfLcap];
+    unsigned int ln;    // entries this workgroup wants to list (may exceed kPfLcap: the rest went to work[] directly)
+    unsigned int gbase;
+    unsigned int dead;  // the walk had been given up when this workgroup began
+};
+__device__ __forceinline__ unsigned int pf_peek(const unsigned int *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void pf_give_up(unsigned int *ctl)
+{
+    __hip_atomic_store(&ctl[kPfFlag], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// A workgroup begins: false if the walk was given up before it started.  (Contains a barrier.)
+__device__ __forceinline__ bool pf_begin(PfShared &sh, const unsigned int *ctl)
+{
+    if (threadIdx.x == 0) {
+        sh.ln = 0;
+        sh.dead = pf_peek(&ctl[kPfFlag]);
+    }
+    __syncthreads();
+    return sh.dead == 0;
+}
+// One row's flagged lanes of a wave (`mask` = ballot of `any`) into the workgroup's list first: one atomic on
+// the global counter per workgroup, not per row.  A workgroup whose list is full (a bright signal fills the rows
+// of its columns) sends the rest of the wave's row straight to the global list, again with one atomic.
+__device__ __forceinline__ void pf_insert(PfShared &sh, unsigned long long mask, bool any, int lane, const WorkItem &w,
+                                          WorkItem *__restrict__ work, unsigned int *__restrict__ ctl, unsigned int limit)
+{
+    unsigned int base = 0;
+    const int leader = __ffsll((long long) mask) - 1;
+    if (lane == leader)
+        base = atomicAdd(&sh.ln, (unsigned int) __popcll(mask));
+    base = __shfl(base, leader);
+    const unsigned int pos = base + (unsigned int) __popcll(mask & ((1ull << lane) - 1ull));
+    if (any && pos < (unsigned int) kPfLcap)
+        sh.lst[pos] = w;
+    const unsigned long long over = __ballot(any && pos >= (unsigned int) kPfLcap);
+    if (over) {
+        unsigned int gb = 0;
+        const int l2 = __ffsll((long long) over) - 1;
+        if (lane == l2)
+            gb = atomicAdd(&ctl[0], (unsigned int) __popcll(over));
+        gb = __shfl(gb, l2);
+        if (any && pos >= (unsigned int) kPfLcap) {
+            const unsigned int gpos = gb + (unsigned int) __popcll(over & ((1ull << lane) - 1ull));
+            if (gpos < limit)
+                work[gpos] = w;
+            else // the global list is full too: the plain sum will run
+                pf_give_up(ctl);
+        }
+    }
+}
+// The workgroup's list goes to the global one (after the barrier that ends the walk).  Whether it goes is
+// decided by one thread: the flag can change between two threads' looks at it, and there is a barrier below.
+constexpr unsigned int kPfNoBase = 0xFFFFFFFFu;
+__device__ __forceinline__ void pf_flush(PfShared &sh, WorkItem *__restrict__ work, unsigned int *__restrict__ ctl, unsigned int limit)
+{
+    const unsigned int n = min(sh.ln, (unsigned int) kPfLcap);
+    if (threadIdx.x == 0) {
+        unsigned int base = kPfNoBase;
+        if (n && !pf_peek(&ctl[kPfFlag])) {
+            base = atomicAdd(&ctl[0], n);
+            if (base + n > limit || base + n < base) { // the list is of no use: nobody will read it
+                pf_give_up(ctl);
+                base = kPfNoBase;
+            }
+        }
+        sh.gbase = base;
+    }
+    __syncthreads();
+    const unsigned int base = sh.gbase;
+    if (base == kPfNoBase)
+        return;
+    for (unsigned int i = threadIdx.x; i < n; i += 256)
+        work[base + i] = sh.lst[i];
+}
 template <int NSTAGES>
 __global__ __launch_bounds__(256) void k_prefilter_lanes(
     const unsigned short *__restrict__ mx, int numz, GroupGrid g, int64_t ngroups,
     const int64_t *__restrict__ rowmx /*[numz][NHS] byte offsets of the source rows in the plane of maxima*/,
     const uint32_t *__restrict__ rowchg, HarmParams prm, WorkItem *__restrict__ work, unsigned int *__restrict__ ctl,
-    unsigned int work_cap, int xcd_remap, const unsigned int *__restrict__ flags)
+    unsigned int limit, int xcd_remap, const unsigned int *__restrict__ flags)
 {
     constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
-    constexpr int LCAP = 2048;
-    __shared__ WorkItem lst[LCAP];
-    __shared__ unsigned int ln, gbase, dead;
+    __shared__ PfShared sh;
     const int lane = threadIdx.x & 63;
     unsigned int tile = blockIdx.x;
     if (xcd_remap) {
-        const unsigned int per = (gridDim.x + 7) / 8;
+        const unsigned int per = (gridDim.x + 7) / 8; // 8 XCDs
         tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
         if ((int64_t) tile * 256 >= ngroups)
             return;
     }
     if (flags[0] != 0) { // negative powers in the plane: the bounds do not hold
         if (blockIdx.x == 0 && threadIdx.x == 0)
-            ctl[1] = 1u;
+            pf_give_up(ctl);
         return;
     }
-    if (threadIdx.x == 0) {
-        ln = 0;
-        dead = 0;
-    }
-    __syncthreads();
+    if (!pf_begin(sh, ctl))
+        return; // given up before this workgroup started
     const int64_t gid = (int64_t) tile * 256 + threadIdx.x;
     const bool live = gid < ngroups;
     const uint32_t gl = live ? (uint32_t) gid : 0u;
@@ -1589,9 +1683,13 @@ __global__ __launch_bounds__(256) void k_prefilter_lanes(
     const char *mbytes = reinterpret_cast<const char *>(mx);
     const int64_t rowb = 2 * g.mxlen;
     uint32_t v0[NHS], v1[NHS];
-    for (int zi = 0; zi < numz; zi++) {
+    // (the first row loads every source -- what rowchg[0] says anyway: spelt out, the compiler knows that no source
+    // value enters the loop undefined, and the kernel needs 62 registers instead of 73: eight waves per SIMD)
+    int zfirst = 0;
+    asm volatile("" : "+s"(zfirst));
+    for (int zi = zfirst; zi < numz; zi++) {
         const uint32_t fm = *reinterpret_cast<const unsigned short *>(mbytes + (size_t) zi * (size_t) rowb + foff);
-        const uint32_t chg = NH > 0 ? rowchg[zi] : 0u;
+        const uint32_t chg = NH == 0 ? 0u : zi == zfirst ? ~0u : rowchg[zi];
         int64_t ro[NHS];
 #pragma unroll
         for (int i = 0; i < NH; i++)
@@ -1626,50 +1724,11 @@ __global__ __launch_bounds__(256) void k_prefilter_lanes(
         }
         any = any && live;
         const unsigned long long mask = __ballot(any);
-        if (mask) { // into the workgroup's list first: one atomic on the global counter per workgroup, not per row
-            unsigned int base = 0;
-            const int leader = __ffsll((long long) mask) - 1;
-            if (lane == leader)
-                base = atomicAdd(&ln, (unsigned int) __popcll(mask));
-            base = __shfl(base, leader);
-            const unsigned int pos = base + (unsigned int) __popcll(mask & ((1ull << lane) - 1ull));
-            const WorkItem w{(uint32_t) zi, (uint32_t) gid};
-            if (any && pos < LCAP)
-                lst[pos] = w;
-            // the workgroup's list is full (a bright signal fills the rows of its columns): the rest of this
-            // wave's row goes straight to the global list, again with one atomic
-            const unsigned long long over = __ballot(any && pos >= LCAP);
-            if (over) {
-                unsigned int gb = 0;
-                const int l2 = __ffsll((long long) over) - 1;
-                if (lane == l2)
-                    gb = atomicAdd(&ctl[0], (unsigned int) __popcll(over));
-                gb = __shfl(gb, l2);
-                if (any && pos >= LCAP) {
-                    const unsigned int gpos = gb + (unsigned int) __popcll(over & ((1ull << lane) - 1ull));
-                    if (gpos < work_cap) {
-                        work[gpos] = w;
-                    } else { // the global list is full too: the plain sum will run, nothing more to do here
-                        ctl[1] = 1u;
-                        dead = 1u;
-                    }
-                }
-            }
-        }
-        if ((zi & 7) == 7 && dead)
-            break;
+        if (mask)
+            pf_insert(sh, mask, any, lane, WorkItem{(uint32_t) zi, (uint32_t) gid}, work, ctl, limit);
     }
     __syncthreads();
-    const unsigned int n = min(ln, (unsigned int) LCAP);
-    if (threadIdx.x == 0 && n)
-        gbase = atomicAdd(&ctl[0], n);
-    __syncthreads();
-    for (unsigned int i = threadIdx.x; i < n; i += 256) {
-        if (gbase + i < work_cap)
-            work[gbase + i] = lst[i];
-        else
-            ctl[1] = 1u;
-    }
+    pf_flush(sh, work, ctl, limit);
 }
 
 // The entries of one source that bound the cells of one group of four fundamental columns (first column cf,
@@ -1710,31 +1769,26 @@ __global__ __launch_bounds__(256) void k_prefilter_pairs(
     const unsigned short *__restrict__ mx, int numz, GroupGrid g, int64_t ngroups,
     const int64_t *__restrict__ rowmx /*[numz][NHS] byte offsets of the source rows in the plane of maxima*/,
     const uint32_t *__restrict__ rowchg, HarmParams prm, WorkItem *__restrict__ work, unsigned int *__restrict__ ctl,
-    unsigned int work_cap, int xcd_remap, const unsigned int *__restrict__ flags)
+    unsigned int limit, int xcd_remap, const unsigned int *__restrict__ flags)
 {
     constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
-    constexpr int LCAP = 2048;
-    __shared__ WorkItem lst[LCAP];
-    __shared__ unsigned int ln, gbase, dead;
+    __shared__ PfShared sh;
     const int lane = threadIdx.x & 63;
     const int64_t npairs = ngroups / NG; // lanes wanted (groups per block and hence in all: even)
     unsigned int tile = blockIdx.x;
     if (xcd_remap) {
-        const unsigned int per = (gridDim.x + 7) / 8;
+        const unsigned int per = (gridDim.x + 7) / 8; // 8 XCDs
         tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
         if ((int64_t) tile * 256 >= npairs)
             return;
     }
     if (flags[0] != 0) { // negative powers in the plane: the bounds do not hold
         if (blockIdx.x == 0 && threadIdx.x == 0)
-            ctl[1] = 1u;
+            pf_give_up(ctl);
         return;
     }
-    if (threadIdx.x == 0) {
-        ln = 0;
-        dead = 0;
-    }
-    __syncthreads();
+    if (!pf_begin(sh, ctl))
+        return; // given up before this workgroup started
     const int64_t pid = (int64_t) tile * 256 + threadIdx.x;
     const bool live = pid < npairs;
     const uint32_t gidA = live ? (uint32_t) NG * (uint32_t) pid : 0u; // the first of the lane's groups
@@ -1824,51 +1878,83 @@ __global__ __launch_bounds__(256) void k_prefilter_pairs(
 #pragma unroll
         for (int k = 0; k < NG; k++) {
             const unsigned long long mask = crossing[k];
-            if (mask) { // into the workgroup's list first: one atomic on the global counter per workgroup, not per row
-                const bool any = (mask >> lane) & 1ull;
-                unsigned int base = 0;
-                const int leader = __ffsll((long long) mask) - 1;
-                if (lane == leader)
-                    base = atomicAdd(&ln, (unsigned int) __popcll(mask));
-                base = __shfl(base, leader);
-                const unsigned int pos = base + (unsigned int) __popcll(mask & ((1ull << lane) - 1ull));
-                const WorkItem wi{(uint32_t) zi, (uint32_t) NG * (uint32_t) pid + (uint32_t) k};
-                if (any && pos < LCAP)
-                    lst[pos] = wi;
-                // the workgroup's list is full (a bright signal fills the rows of its columns): the rest of this
-                // wave's row goes straight to the global list, again with one atomic
-                const unsigned long long over = __ballot(any && pos >= LCAP);
-                if (over) {
-                    unsigned int gb = 0;
-                    const int l2 = __ffsll((long long) over) - 1;
-                    if (lane == l2)
-                        gb = atomicAdd(&ctl[0], (unsigned int) __popcll(over));
-                    gb = __shfl(gb, l2);
-                    if (any && pos >= LCAP) {
-                        const unsigned int gpos = gb + (unsigned int) __popcll(over & ((1ull << lane) - 1ull));
-                        if (gpos < work_cap) {
-                            work[gpos] = wi;
-                        } else { // the global list is full too: the plain sum will run, nothing more to do here
-                            ctl[1] = 1u;
-                            dead = 1u;
-                        }
-                    }
-                }
-            }
+            if (mask)
+                pf_insert(sh, mask, (mask >> lane) & 1ull, lane, WorkItem{(uint32_t) zi, (uint32_t) NG * (uint32_t) pid + (uint32_t) k},
+                          work, ctl, limit);
         }
-        if ((zi & 7) == 7 && dead)
-            break;
     }
     __syncthreads();
-    const unsigned int n = min(ln, (unsigned int) LCAP);
-    if (threadIdx.x == 0 && n)
-        gbase = atomicAdd(&ctl[0], n);
+    pf_flush(sh, work, ctl, limit);
+}
+
+// How long would the list be?  Asked before the walk (see the note on the control words): every lane takes one
+// (row, group) -- sample k of nsamples: group k * gstep mod ngroups, gstep odd and near the golden section of
+// ngroups, so that the samples are spread evenly over the columns; row a multiplicative hash of k -- and works
+// out its bound sums exactly as k_prefilter_lanes does for that row.  The last workgroup to finish scales the
+// count: more than sample_limit of the samples listed, and the flag goes up.
+template <int NSTAGES>
+__global__ __launch_bounds__(256) void k_prefilter_sample(
+    const unsigned short *__restrict__ mx, int numz, GroupGrid g, int64_t ngroups, const int64_t *__restrict__ rowmx,
+    HarmParams prm, unsigned int *__restrict__ ctl, unsigned int nsamples, unsigned int gstep, unsigned int sample_limit,
+    const unsigned int *__restrict__ flags)
+{
+    constexpr int NHS = HarmShape<NSTAGES>::NHS;
+    __shared__ unsigned int found;
+    if (flags[0] != 0) { // negative powers in the plane: the bounds do not hold
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            pf_give_up(ctl);
+        return;
+    }
+    if (threadIdx.x == 0)
+        found = 0;
     __syncthreads();
-    for (unsigned int i = threadIdx.x; i < n; i += 256) {
-        if (gbase + i < work_cap)
-            work[gbase + i] = lst[i];
-        else
-            ctl[1] = 1u;
+    const unsigned int k = blockIdx.x * 256 + threadIdx.x;
+    const bool live = k < nsamples;
+    const uint32_t gl = (uint32_t) (((uint64_t) (live ? k : 0u) * gstep) % (uint64_t) ngroups);
+    const int zi = (int) ((((live ? k : 0u) * 2654435761u) >> 8) % (uint32_t) numz);
+    const uint32_t sb = gl / (uint32_t) kGpb;
+    const int lg = (int) (gl % (uint32_t) kGpb);
+    const int lfirst = max(4 * lg - g.a, 0), llast = min(4 * lg - g.a + 3, kUseLen - 1);
+    const uint32_t cf = (uint32_t) g.search_col0 + sb * (uint32_t) kUseLen + (uint32_t) lfirst, cl = cf + (uint32_t) (llast - lfirst);
+    const char *mbytes = reinterpret_cast<const char *>(mx);
+    const size_t rowb = 2 * (size_t) g.mxlen;
+    const uint32_t fm = *reinterpret_cast<const unsigned short *>(mbytes + (size_t) zi * rowb +
+                                                                  2 * ((size_t) (g.nprepop + sb) * kGpb + (size_t) lg));
+    float p = bound_value(fm);
+    bool any = !(p <= prm.powcut[0]);
+    {
+        int i = 0;
+#pragma unroll
+        for (int s = 1; s < NSTAGES; s++) {
+#pragma unroll
+            for (int h = 1; h < (1 << s); h += 2) {
+                uint32_t e0, d;
+                source_entries(g, cf, cl, s, h, e0, d);
+                if (d > 1) { // not covered by two consecutive entries: always listed
+                    any = true;
+                    e0 = 0;
+                    d = 0;
+                }
+                const char *src = mbytes + rowmx[(size_t) zi * NHS + i];
+                const uint32_t a = *reinterpret_cast<const unsigned short *>(src + 2 * (size_t) e0);
+                const uint32_t b = *reinterpret_cast<const unsigned short *>(src + 2 * (size_t) (e0 + d));
+                p += bound_value(max(a, b));
+                i++;
+            }
+            any |= !(p <= prm.powcut[s]); // a NaN (the bound of an infinite power) counts as a crossing
+        }
+    }
+    const unsigned long long mask = __ballot(any && live);
+    if (mask && (threadIdx.x & 63) == 0)
+        atomicAdd(&found, (unsigned int) __popcll(mask));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long old = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(ctl + 32),
+                                                              (unsigned long long) found | (1ull << 40), __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_AGENT);
+        // the last one sees everybody's count: they all went through this one word
+        if ((old >> 40) + 1 == gridDim.x && (old & ((1ull << 40) - 1)) + found > sample_limit)
+            pf_give_up(ctl);
     }
 }
 
@@ -1881,7 +1967,13 @@ __global__ __launch_bounds__(256) void k_flagged_exact(
     unsigned int *__restrict__ count, unsigned int max_hits)
 {
     constexpr int NHS = HarmShape<NSTAGES>::NHS;
-    if (ctl[1] != 0)
+    // what became of the list, for the host, beside the launch's hit count: count[4] entries, [5] of no use, [8] = 1
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        count[4] = ctl[0];
+        count[5] = ctl[kPfFlag];
+        count[8] = 1u;
+    }
+    if (ctl[kPfFlag] != 0)
         return; // the plain sum runs instead
     const unsigned int n = min(ctl[0], work_cap);
     const int lane = threadIdx.x & 63;

@@ -83,6 +83,9 @@ constexpr size_t kScratchBlockfftBytes = (size_t) kNoAllocBlocks * 8192 * sizeof
 constexpr size_t kScratchBytes = kScratchDescBytes + kScratchBlockfftBytes; // 1 MiB + 512 B
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 constexpr int kMaxDevices = 64;
+// A launch's hit counter is word 0 of a small block; words 4..8 tell the host what became of the coarse
+// bound's list (written by k_flagged_exact).
+constexpr size_t kCountBytes = 64;
 static unsigned char *g_scratch_ptr[kMaxDevices];
 static std::mutex g_scratch_mutex;
 
@@ -108,6 +111,10 @@ struct Tuning {
     int use_graph = 1;      // small searches: one captured graph per launch instead of nine stream operations
     int hs_bound = 1;       // harmonic sum over 16-bit upper bounds of the plane, exact where a bound crosses
     int pf_list_cap = 0;    // entries of the coarse bound's list of (row, group)s; 0: 1/64 of all of them (tests lower it)
+    int pf_limit_ppm = 10000; // the coarse bound's list is of no use beyond this many entries per million (row, group)s: the
+                            // walk is given up and the bounded sum runs over the whole plane
+    int pf_sample = 1;      // ask a sample of the (row, group)s how long the list would be before walking them all
+    int pf_memory = 1;      // a context whose coarse bound was given up leaves it out of its next trials (4, 8, ... 64 of them)
     int pf_pairs = 1;       // coarse bound from 8-byte loads: 1 two adjacent groups per lane up to 8 harmonics, 2: with 16 too,
                             // 3: one group per lane, 0: never
                             // (0: off, float plane only; 1: on; 2 / 3: on, one / two columns per lane forced)
@@ -188,6 +195,7 @@ struct accelgpu_ctx {
     unsigned short *d_hi = nullptr, *d_lo = nullptr;
     size_t hilo_cap = 0;               // cells in each
     unsigned int *d_flags = nullptr;
+    bool host_wrote_outside = false;   // a host wrote plane cells that a whole plane generation does not rewrite
     int64_t *d_rowoff = nullptr; // [numz][NH] byte offsets of the sub-harmonic source rows
     size_t rowoff_cap = 0;
     uint32_t *d_rowchg = nullptr; // [numz] bit i: source row of harmonic i differs from row zi-1
@@ -206,6 +214,11 @@ struct accelgpu_ctx {
     bool pf_ready = false;    // the three buffers above are sized for the search that is set
     bool mx_valid = false;    // the maxima describe the plane as it is (written by the last whole plane generation)
     bool mx_fix_pending = false; // ... once k_group_fix has run
+    // What the coarse bound's last outcomes say about the next trial (the trials of one batch are alike): after a
+    // launch whose list was given up, the next pf_backoff launches go without it, then one tries again.
+    int pf_backoff = 0, pf_skip = 0;
+    bool pf_off = false;      // this launch goes without (decided when it is launched)
+    int64_t pf_last_listed = 0; // the last collected launch: entries listed, -1 given up, -2 the coarse bound did not run
     size_t rowhalf_cap = 0;
 
     // hits
@@ -222,6 +235,7 @@ struct accelgpu_ctx {
         size_t prefetch = 0;                         // hits copied back speculatively at launch
         size_t cap = 0;                              // room in d_hits / h_hits
         uint64_t serial = 0;                         // which launch this is (see plane_serial)
+        bool pf_counted = false;                     // the coarse bound's outcome has been taken note of
     } slots[2];
     int head = 0, tail = 0, inflight = 0;            // FIFO of launched, uncollected trials
     uint64_t launch_serial = 0;                      // launches so far
@@ -231,6 +245,8 @@ struct accelgpu_ctx {
     // once per (hit slot, spectrum buffer) and replayed with one call.
     struct LaunchGraph {
         int slot = 0;
+        bool pf_off = false;
+        bool mx_valid_after = false, mx_fix_after = false; // the state of the group maxima once the graph has run
         const c32 *fft = nullptr;
         int64_t numbins = 0;
         hipGraph_t graph = nullptr;
@@ -729,10 +745,12 @@ int ensure_prefilter(accelgpu_ctx *ctx)
         HIPCHK(hipMemcpy(ctx->d_rowmx, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     }
     const size_t ngroups = (size_t) ctx->nsearch * accelk::kGpb;
-    const size_t want = std::max<size_t>((size_t) 1 << 20, (size_t) ctx->numz * ngroups / 64);
+    // (pf_list_cap above the default makes room for more: measurements of what long lists cost)
+    const size_t want = std::max<size_t>(std::max<size_t>((size_t) 1 << 20, (size_t) ctx->numz * ngroups / 64),
+                                         (size_t) std::max(ctx->tune.pf_list_cap, 0));
     if ((rc = dev_reserve(&ctx->d_work, &ctx->work_cap, want, false, ctx->stream))) return rc;
     if (!ctx->d_ctl)
-        HIPCHK(hipMalloc((void **) &ctx->d_ctl, 64));
+        HIPCHK(hipMalloc((void **) &ctx->d_ctl, accelk::kPfCtlWords * sizeof(unsigned int)));
     ctx->pf_ready = true;
     return ACCELGPU_OK;
 }
@@ -741,17 +759,32 @@ int ensure_prefilter(accelgpu_ctx *ctx)
 // generation writes the group maxima; planes too small to fill the device with a quarter of the
 // lanes, two-stage searches and chunked sums keep the plain bounded sum.)  hs_bound = 4 forces it where
 // it can run at all (the maxima are then taken from the plane if plane generation did not write them).
-bool prefilter_wanted(const accelgpu_ctx *ctx)
+// The shape part of that question (accelgpu_coarse_bound_applies).
+bool coarse_bound_shape_ok(int numharmstages, int64_t search_columns, int64_t rlen, int fftlen, bool forced)
 {
-    if (!bounds_in_use(ctx) || ctx->setup.numharmstages < 2 || ctx->tune.hs_chunk_blocks > 0)
+    if (numharmstages < 2 || numharmstages > (forced ? 6 : 5))
         return false;
-    if (ctx->tune.hs_bound == 4)
-        return true;
+    if (rlen <= 0 || rlen >= ((int64_t) 1 << 32))
+        return false; // its kernels count columns, groups and entries in 32 bits (the sums proper index in 64)
+    if (forced)
+        return true; // (the maxima are then taken from the plane if plane generation does not write them)
     // 2 to 16 harmonics: with 32 the sum of 32 maxima is too loose a bound (most groups are listed).  (With 2 and 4 it
     // pays since a lane sums two adjacent groups from 8-byte loads: 0.40 against 0.93 ms and 0.48 against 1.27 ms
     // on a 2^23-point, zmax 200 plane, for 0.15-0.19 ms more of plane generation.)
-    return ctx->tune.hs_bound == 1 && ctx->setup.numharmstages >= 2 && ctx->setup.numharmstages <= 5 &&
-           ctx->ncols >= ((int64_t) 1 << 22) && ctx->fftlen == 8192 && ctx->tune.corr_pair != 0;
+    return search_columns >= ((int64_t) 1 << 22) && fftlen == 8192;
+}
+bool prefilter_wanted(const accelgpu_ctx *ctx)
+{
+    if (!bounds_in_use(ctx) || ctx->tune.hs_chunk_blocks > 0)
+        return false;
+    const bool forced = ctx->tune.hs_bound == 4;
+    if (!coarse_bound_shape_ok(ctx->setup.numharmstages, ctx->ncols, ctx->setup.rlen, ctx->fftlen, forced))
+        return false;
+    if (forced)
+        return true;
+    if (ctx->pf_off)
+        return false; // it was given up on this context's last trials
+    return ctx->tune.hs_bound == 1 && ctx->tune.corr_pair != 0;
 }
 bool maxima_from_plane_generation(const accelgpu_ctx *ctx)
 {
@@ -764,9 +797,10 @@ int launch_prefilter(accelgpu_ctx *ctx, int nstages, const accelk::HarmParams &p
     int rc = ensure_prefilter(ctx);
     if (rc) return rc;
     const accelk::GroupGrid &g = ctx->grid;
-    HIPCHK(hipMemsetAsync(ctx->d_ctl, 0, 64, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_ctl, 0, accelk::kPfCtlWords * sizeof(unsigned int), ctx->stream));
     if (!ctx->mx_valid) { // the plane was not written by a plane generation that keeps the maxima: from the plane
-        const dim3 grid((unsigned) ((accelk::kGpb + 255) / 256), (unsigned) ctx->nblk, (unsigned) ctx->numz);
+        // (blocks folded into grid.x: a long series has more of them than grid.y may count)
+        const dim3 grid((unsigned) ((accelk::kGpb + 255) / 256) * (unsigned) ctx->nblk, 1u, (unsigned) ctx->numz);
         hipLaunchKernelGGL(accelk::k_group_max, grid, dim3(256), 0, ctx->stream, ctx->d_hi, ctx->setup.rlen, ctx->d_blk_col,
                            ctx->d_blk_ncols, g, ctx->d_mx);
         ctx->mx_valid = true;
@@ -790,8 +824,21 @@ int launch_prefilter(accelgpu_ctx *ctx, int nstages, const accelk::HarmParams &p
     unsigned int wcap = (unsigned int) std::min<size_t>(ctx->work_cap, 0xFFFFFFFFu);
     if (ctx->tune.pf_list_cap > 0)
         wcap = std::min(wcap, (unsigned int) ctx->tune.pf_list_cap);
+    // Beyond this many entries the list costs more than the bounded sum over the whole plane it replaces (every
+    // entry is four exact column sums): the kernels give the walk up as soon as they see it coming.
+    const double all_entries = (double) ctx->numz * (double) ngroups;
+    if (ctx->tune.hs_bound != 4) // (forced: as long a list as there is room for)
+        wcap = (unsigned int) std::min<double>((double) wcap, std::max(1.0, all_entries * 1e-6 * std::max(ctx->tune.pf_limit_ppm, 0)));
+    // ... by asking a sample of the (row, group)s before the walk (k_prefilter_sample): 2^17 of them put the list's
+    // length within a few per cent where it matters (a list at the limit has hundreds of them), in 20 microseconds
+    const unsigned int nsamples = (unsigned int) std::min<double>(131072.0, all_entries);
+    unsigned int gstep = (unsigned int) ((double) ngroups * 0.6180339887) | 1u;
+    const unsigned int sample_limit = (unsigned int) std::min<double>(4294967295.0, std::ceil((double) wcap * (double) nsamples / all_entries));
 #define LAUNCH_PF(NS)                                                                                          \
     do {                                                                                                       \
+        if (ctx->tune.pf_sample)                                                                               \
+            hipLaunchKernelGGL((accelk::k_prefilter_sample<NS>), dim3((nsamples + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_mx, \
+                               ctx->numz, g, ngroups, ctx->d_rowmx, prm, ctx->d_ctl, nsamples, gstep, sample_limit, ctx->d_flags); \
         if (per_lane == 2)                                                                                     \
             hipLaunchKernelGGL((accelk::k_prefilter_pairs<(NS > 5 ? 5 : NS), 2>), dim3(nt), dim3(256), 0, ctx->stream, ctx->d_mx, ctx->numz, g, \
                                ngroups, ctx->d_rowmx, ctx->d_rowchg, prm, ctx->d_work, ctx->d_ctl, wcap, remap, ctx->d_flags); \
@@ -1041,6 +1088,16 @@ int check_ready(accelgpu_ctx *ctx, bool need_fft, bool settle = true)
     return ACCELGPU_OK;
 }
 
+// Does the launch that starts now go without the coarse bound?  (See note_prefilter_outcome.)
+void decide_prefilter(accelgpu_ctx *ctx)
+{
+    ctx->pf_off = false;
+    if (ctx->tune.pf_memory && ctx->pf_skip > 0) {
+        ctx->pf_off = true;
+        ctx->pf_skip--;
+    }
+}
+
 int queue_fill(accelgpu_ctx *ctx)
 {
     if (ctx->nblk_active == 0)
@@ -1050,6 +1107,9 @@ int queue_fill(accelgpu_ctx *ctx)
     if (rc) return rc;
     ctx->mx_valid = false;
     if (bounds_in_use(ctx)) {
+        // every cell a host may have written a negative power into is rewritten now: the bounds hold again
+        if (ctx->nblk_active == ctx->nblk && !ctx->host_wrote_outside)
+            HIPCHK(hipMemsetAsync(ctx->d_flags, 0, 64, ctx->stream));
         if (maxima_from_plane_generation(ctx)) {
             if ((rc = ensure_prefilter(ctx))) return rc;
             rc = launch_correlate(ctx, ctx->nblk_active, ctx->d_blockfft, ctx->d_blk_col, ctx->d_blk_ncols, nullptr,
@@ -1104,7 +1164,7 @@ int launch_as_graph(accelgpu_ctx *ctx, int si)
     accelgpu_ctx::HitSlot &sl = ctx->slots[si];
     accelgpu_ctx::LaunchGraph *g = nullptr;
     for (auto &e : ctx->graphs)
-        if (e.slot == si && e.fft == ctx->d_fft && e.numbins == ctx->numbins)
+        if (e.slot == si && e.fft == ctx->d_fft && e.numbins == ctx->numbins && e.pf_off == ctx->pf_off)
             g = &e;
     if (!g) {
         if (ctx->graphs.size() >= 12) { // least recently used one out
@@ -1119,48 +1179,62 @@ int launch_as_graph(accelgpu_ctx *ctx, int si)
         e.slot = si;
         e.fft = ctx->d_fft;
         e.numbins = ctx->numbins;
+        e.pf_off = ctx->pf_off;
         if (prefilter_wanted(ctx)) { // its buffers are allocated and its table copied outside the capture
             int rc = ensure_prefilter(ctx);
             if (rc) return rc;
         }
+        // the body below records kernels, it runs none: what it notes about the maxima holds only once the
+        // graph has been launched
+        const bool mx_valid0 = ctx->mx_valid, mx_fix0 = ctx->mx_fix_pending;
         HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
         auto body = [&]() -> int {
-            HIPCHK(hipMemsetAsync(sl.d_count, 0, sizeof(unsigned int), ctx->stream));
+            HIPCHK(hipMemsetAsync(sl.d_count, 0, kCountBytes, ctx->stream));
             int rc = queue_fill(ctx);
             if (rc) return rc;
             rc = launch_harmsum<false>(ctx, ctx->setup.numharmstages, ctx->col0, (int64_t) ctx->nsearch * ACCELGPU_USELEN,
                                        nullptr, 0, HitTarget{sl.d_hits, sl.d_count, sl.cap});
             if (rc) return rc;
-            HIPCHK(hipMemcpyAsync(sl.h_count, sl.d_count, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipMemcpyAsync(sl.h_count, sl.d_count, kCountBytes, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipMemcpyAsync(sl.h_hits, sl.d_hits, prefetch_hits(ctx, sl) * sizeof(DevHit), hipMemcpyDeviceToHost,
                                   ctx->stream));
             return ACCELGPU_OK;
         };
         const int rc = body();
         const hipError_t ee = hipStreamEndCapture(ctx->stream, &e.graph); // always: the stream must leave capture mode
+        e.mx_valid_after = ctx->mx_valid;
+        e.mx_fix_after = ctx->mx_fix_pending;
+        ctx->mx_valid = mx_valid0;
+        ctx->mx_fix_pending = mx_fix0;
         if (rc) {
             if (e.graph) (void) hipGraphDestroy(e.graph);
             return rc;
         }
         HIPCHK(ee);
-        HIPCHK(hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
+        if (hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0) != hipSuccess) {
+            (void) hipGraphDestroy(e.graph);
+            set_error("hipGraphInstantiate failed: %s", hipGetErrorString(hipGetLastError()));
+            return ACCELGPU_ERR_HIP;
+        }
         ctx->graphs.push_back(e);
         g = &ctx->graphs.back();
     }
     g->used = ++ctx->graph_clock;
     HIPCHK(hipGraphLaunch(g->exec, ctx->stream));
+    ctx->mx_valid = g->mx_valid_after; // what a whole fill and sum leave behind
+    ctx->mx_fix_pending = g->mx_fix_after;
     return ACCELGPU_OK;
 }
 
 int queue_search(accelgpu_ctx *ctx)
 {
-    HIPCHK(hipMemsetAsync(ctx->d_count, 0, sizeof(unsigned int), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_count, 0, kCountBytes, ctx->stream));
     int rc = launch_harmsum<false>(ctx, ctx->setup.numharmstages,
                                    ctx->col0 + (int64_t) ctx->range_first * ACCELGPU_USELEN,
                                    (int64_t) ctx->range_count * ACCELGPU_USELEN, nullptr, 0,
                                    slot_target(ctx));
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(ctx->h_count, ctx->d_count, sizeof(unsigned int), hipMemcpyDeviceToHost,
+    HIPCHK(hipMemcpyAsync(ctx->h_count, ctx->d_count, kCountBytes, hipMemcpyDeviceToHost,
                           ctx->stream));
     return ACCELGPU_OK;
 }
@@ -1173,6 +1247,26 @@ inline uint64_t visit_key(int64_t rind, uint32_t stage, uint32_t zind, int64_t c
     return (((block * 8 + stage) * 2048 + zind) << 13) | col;                  // stage < 2^3, zind < 2^11
 }
 
+// What the coarse bound of a finished launch did decides whether the next launches try it: given up ->
+// the next 4 launches go without (8, 16 ... 64 when it is given up again right after), a list that served ->
+// it stays.  The trials of one batch are alike (DM trials of one beam), and a launch that gives up has
+// still paid for part of the walk and for the maxima plane generation wrote.
+void note_prefilter_outcome(accelgpu_ctx *ctx, const unsigned int *words)
+{
+    if (!words[8]) {
+        ctx->pf_last_listed = -2;
+        return;
+    }
+    if (words[5]) {
+        ctx->pf_last_listed = -1;
+        ctx->pf_backoff = ctx->tune.pf_memory ? std::min(std::max(2 * ctx->pf_backoff, 4), 64) : 0;
+        ctx->pf_skip = ctx->pf_backoff;
+    } else {
+        ctx->pf_last_listed = (int64_t) words[4];
+        ctx->pf_backoff = 0;
+    }
+}
+
 // Waits for the search launched into slot `si` and returns its hits sorted into the
 // reference's visiting order.  If the compaction overflowed the slot's buffer the search
 // is run again into a larger one: from the plane if it still holds this trial, after
@@ -1183,6 +1277,10 @@ int finish_search(accelgpu_ctx *ctx, int si, accelgpu_hit *hits, int64_t max_hit
     accelgpu_ctx::HitSlot &sl = ctx->slots[si];
     select_slot(ctx, si);
     HIPCHK(hipEventSynchronize(sl.done));
+    if (!sl.pf_counted) { // once per launch (a collect can be repeated)
+        sl.pf_counted = true;
+        note_prefilter_outcome(ctx, sl.h_count);
+    }
     size_t n = *sl.h_count;
     size_t have = std::min(sl.prefetch, n);
     sl.prefetch = 0;
@@ -1262,7 +1360,8 @@ const TuneName kTuneNames[] = {
     {"std_table", &Tuning::std_table},       {"std_blocks", &Tuning::std_blocks},
     {"opt_nt", &Tuning::opt_nt},             {"use_graph", &Tuning::use_graph},
     {"hs_bound", &Tuning::hs_bound},         {"pf_list_cap", &Tuning::pf_list_cap},
-    {"pf_pairs", &Tuning::pf_pairs},
+    {"pf_pairs", &Tuning::pf_pairs},         {"pf_limit_ppm", &Tuning::pf_limit_ppm},
+    {"pf_memory", &Tuning::pf_memory},       {"pf_sample", &Tuning::pf_sample},
 };
 
 void tuning_from_env(Tuning *t)
@@ -1298,6 +1397,10 @@ double accelgpu_candidate_sigma(double power, int numsum, double numtrials)
 double accelgpu_power_for_sigma(double sigma, int numsum, double numtrials)
 {
     return accelhost::power_for_sigma(sigma, numsum, numtrials);
+}
+int accelgpu_coarse_bound_applies(int numharmstages, int64_t search_columns, int64_t rlen, int fftlen, int forced)
+{
+    return coarse_bound_shape_ok(numharmstages, search_columns, rlen, fftlen, forced != 0) ? 1 : 0;
 }
 int accelgpu_plan(int64_t numbins, int64_t N, double dt, int zmax, int numharm, double sigma,
                   double flo, double fhi, int64_t lobin, accelgpu_setup *out)
@@ -1373,8 +1476,9 @@ int accelgpu_create(accelgpu_ctx **out, int device)
         HIPCHK(hipStreamCreateWithPriority(&ctx->opt_stream, hipStreamNonBlocking, greatest));
     }
     for (auto &sl : ctx->slots) {
-        HIPCHK(hipMalloc((void **) &sl.d_count, sizeof(unsigned int)));
-        HIPCHK(hipHostMalloc((void **) &sl.h_count, sizeof(unsigned int)));
+        HIPCHK(hipMalloc((void **) &sl.d_count, kCountBytes));
+        HIPCHK(hipHostMalloc((void **) &sl.h_count, kCountBytes));
+        memset(sl.h_count, 0, kCountBytes);
         HIPCHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sl.kernels, hipEventDisableTiming));
     }
@@ -1488,6 +1592,10 @@ int accelgpu_set_tuning(accelgpu_ctx *ctx, const char *name, int value)
         if (!strcmp(name, k.name)) {
             ctx->tune.*(k.field) = value;
             drop_graphs(ctx);
+            if (k.field == &Tuning::pf_list_cap)
+                ctx->pf_ready = false; // the list is sized again at the next launch
+            if (k.field == &Tuning::pf_memory || k.field == &Tuning::hs_bound)
+                ctx->pf_skip = ctx->pf_backoff = 0;
             if (k.field == &Tuning::hs_bound && ctx->have_search && ctx->inmem &&
                 want_split(ctx, ctx->setup.numharmstages) != ctx->split) {
                 // the plane changes its layout: set up afresh (an empty plane, as after accelgpu_set_search)
@@ -1511,12 +1619,20 @@ int accelgpu_get_tuning(accelgpu_ctx *ctx, const char *name, int *value)
         return ACCELGPU_OK;
     }
     if (!strcmp(name, "pf_listed")) { // read-only: (row, group)s the last coarse bound listed; -1: list of no use
-        unsigned int c[2] = {0, 0};
+        unsigned int c[accelk::kPfCtlWords] = {};
         if (ctx->d_ctl) {
             HIPCHK(hipStreamSynchronize(ctx->stream));
             HIPCHK(hipMemcpy(c, ctx->d_ctl, sizeof(c), hipMemcpyDeviceToHost));
         }
-        *value = c[1] ? -1 : (int) std::min<unsigned int>(c[0], 0x7FFFFFFFu);
+        *value = c[accelk::kPfFlag] ? -1 : (int) std::min<unsigned int>(c[0], 0x7FFFFFFFu);
+        return ACCELGPU_OK;
+    }
+    if (!strcmp(name, "pf_last_listed")) { // read-only: the same for the last COLLECTED launch, without touching the device; -2: it did not run
+        *value = (int) std::min<int64_t>(ctx->pf_last_listed, 0x7FFFFFFF);
+        return ACCELGPU_OK;
+    }
+    if (!strcmp(name, "pf_skip")) { // read-only: launches still to go without the coarse bound after it was given up
+        *value = ctx->pf_skip;
         return ACCELGPU_OK;
     }
     if (!strcmp(name, "hs_prefilter_active")) { // read-only: does the coarse bound (group maxima) run in front of the sum?
@@ -1916,6 +2032,7 @@ int set_search_impl(accelgpu_ctx *ctx, const accelgpu_setup *s, int norm_type, f
             HIPCHK(hipMemsetAsync(ctx->d_hi, 0, plane_elems * sizeof(unsigned short), ctx->stream));
             HIPCHK(hipMemsetAsync(ctx->d_lo, 0, plane_elems * sizeof(unsigned short), ctx->stream));
             HIPCHK(hipMemsetAsync(ctx->d_flags, 0, 64, ctx->stream));
+            ctx->host_wrote_outside = false;
         }
     } else {
         if (ctx->d_hi && (rc = release_plane(ctx))) return rc;
@@ -2048,6 +2165,7 @@ int accelgpu_fill_plane(accelgpu_ctx *ctx)
     if ((rc = check_ready(ctx, true))) return rc;
     if ((rc = need_plane(ctx))) return rc;
     ctx->plane_serial = 0; // no launched trial's plane any more: a repeat of one regenerates its own
+    decide_prefilter(ctx);
     if ((rc = queue_fill(ctx))) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return ACCELGPU_OK;
@@ -2074,6 +2192,7 @@ int accelgpu_search_plane(accelgpu_ctx *ctx, accelgpu_hit *hits, int64_t max_hit
     select_slot(ctx, si);
     ctx->slots[si].prefetch = 0;
     ctx->slots[si].serial = ctx->plane_serial; // searches the plane as it stands
+    ctx->slots[si].pf_counted = false;
     if ((rc = queue_search(ctx))) return rc;
     HIPCHK(hipEventRecord(ctx->slots[si].done, ctx->stream));
     return finish_search(ctx, si, hits, max_hits, n_hits);
@@ -2096,6 +2215,8 @@ int accelgpu_run_launch(accelgpu_ctx *ctx)
     sl.fft = ctx->d_fft;
     sl.numbins = ctx->numbins;
     sl.serial = ++ctx->launch_serial;
+    sl.pf_counted = false;
+    decide_prefilter(ctx);
     if (ctx->range_count > 0) {
         if ((rc = spectrum_ready(ctx, ctx->stream))) return rc;
         const bool whole_grid = ctx->nblk_active == ctx->nblk && ctx->range_first == 0 && ctx->range_count == ctx->nsearch;
@@ -2110,7 +2231,7 @@ int accelgpu_run_launch(accelgpu_ctx *ctx)
             ctx->inflight++;
             return ACCELGPU_OK;
         }
-        HIPCHK(hipMemsetAsync(ctx->d_count, 0, sizeof(unsigned int), ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->d_count, 0, kCountBytes, ctx->stream));
         if (ctx->tune.hs_chunk_blocks > 0 && whole_grid) {
             if ((rc = queue_fill_and_sum_chunked(ctx, ctx->tune.hs_chunk_blocks, slot_target(ctx)))) return rc;
             ctx->plane_serial = sl.serial;
@@ -2127,7 +2248,7 @@ int accelgpu_run_launch(accelgpu_ctx *ctx)
         // trial's kernels never queue behind PCIe transfers
         HIPCHK(hipEventRecord(sl.kernels, ctx->stream));
         HIPCHK(hipStreamWaitEvent(ctx->copy_stream, sl.kernels, 0));
-        HIPCHK(hipMemcpyAsync(sl.h_count, sl.d_count, sizeof(unsigned int), hipMemcpyDeviceToHost,
+        HIPCHK(hipMemcpyAsync(sl.h_count, sl.d_count, kCountBytes, hipMemcpyDeviceToHost,
                               ctx->copy_stream));
         // speculative copy of the head of the hit buffer: usually all of them
         const size_t pre = prefetch_hits(ctx, sl);
@@ -2234,16 +2355,16 @@ int accelgpu_fund_block(accelgpu_ctx *ctx, double startr, float *powers, int32_t
 
 // accelgpu_fund_block() for callers that cannot allocate: up to kNoAllocBlocks blocks per
 // call, block spectra and descriptors in this device's `scratch` array, powers into the
-// caller's device buffer.  No hipMalloc/hipFree, no host-device copies, and no host wait unless
-// an asynchronous upload of the current spectrum is still on its way: the work is queued on
-// the context's stream.  Calls on one GPU share that GPU's array, so
+// caller's device buffer.  No hipMalloc/hipFree, no host-device copies and no host wait (the
+// stream waits for an asynchronous upload of the current spectrum that is still on its way):
+// the work is queued on the context's stream.  Calls on one GPU share that GPU's array, so
 // calls that overlap in time there (two contexts, two streams) race.
 int accelgpu_fund_blocks_noalloc(accelgpu_ctx *ctx, const double *startr, int32_t nblocks,
                                  float *powers_dev, int32_t *rlo_out)
 {
     int rc = use(ctx);
     if (rc) return rc;
-    if ((rc = check_ready(ctx, true))) return rc;
+    if ((rc = check_ready(ctx, true, false))) return rc;
     if (!startr || !powers_dev || nblocks < 1) {
         set_error("accelgpu_fund_blocks_noalloc: null argument or no blocks");
         return ACCELGPU_ERR_ARG;
@@ -2256,11 +2377,14 @@ int accelgpu_fund_blocks_noalloc(accelgpu_ctx *ctx, const double *startr, int32_
     static_assert(kScratchBlockfftBytes >= (size_t) kNoAllocBlocks * (16384 / 2) * sizeof(c32),
                   "working memory sized for the longest plan");
     hipPointerAttribute_t attr;
-    if (hipPointerGetAttributes(&attr, powers_dev) != hipSuccess || attr.type != hipMemoryTypeDevice) {
+    if (hipPointerGetAttributes(&attr, powers_dev) != hipSuccess || attr.type != hipMemoryTypeDevice ||
+        attr.device != ctx->device) {
         (void) hipGetLastError();
-        set_error("accelgpu_fund_blocks_noalloc: the output must be device memory");
+        set_error("accelgpu_fund_blocks_noalloc: the output must be device memory of the context's GPU (%d)", ctx->device);
         return ACCELGPU_ERR_ARG;
     }
+    // a spectrum still on its way (accelgpu_load_fft_async): the stream waits for it, not the host
+    if ((rc = spectrum_ready(ctx, ctx->stream))) return rc;
     unsigned char *base = g_scratch_ptr[ctx->device];
     if (!base) {
         set_error("accelgpu_fund_blocks_noalloc: no working memory on device %d", ctx->device);
@@ -2321,6 +2445,15 @@ int accelgpu_summed_block(accelgpu_ctx *ctx, int block, int stage, float *powers
     return ACCELGPU_OK;
 }
 
+// A host is about to write plane columns [col, col + count): does a whole plane generation rewrite them all?
+static void note_host_write(accelgpu_ctx *ctx, int64_t col, int64_t count)
+{
+    const int64_t lo = ctx->nblk > 0 ? ctx->h_blk_col[0] : 0;
+    const int64_t hi = ctx->col0 + (int64_t) ctx->nsearch * ACCELGPU_USELEN;
+    if (ctx->nblk == 0 || col < lo || col + count > hi)
+        ctx->host_wrote_outside = true;
+}
+
 static int stage_of(int numharm)
 {
     int st = 0;
@@ -2352,6 +2485,7 @@ int accelgpu_fund_to_ffdotplane(accelgpu_ctx *ctx, const float *powers, int32_t 
     }
     ctx->plane_serial = 0;
     ctx->mx_valid = false; // the group maxima no longer describe the plane
+    note_host_write(ctx, col, ACCELGPU_USELEN);
     if (ctx->split) {
         // through the block buffer: the floats are cut into the two planes of halves on the device
         if ((rc = upload_block(ctx, powers))) return rc;
@@ -2510,6 +2644,7 @@ int accelgpu_put_plane(accelgpu_ctx *ctx, int zind, int64_t col, int64_t count, 
     if ((rc = plane_span(ctx, zind, col, count))) return rc;
     ctx->plane_serial = 0;
     ctx->mx_valid = false; // the group maxima no longer describe the plane
+    note_host_write(ctx, col, count);
     if (ctx->split) {
         if (count == 0)
             return ACCELGPU_OK;

@@ -257,3 +257,111 @@ def test_knob_reports_whether_the_bounds_are_in_use(gpu):
     assert gpu.get_tuning("hs_bound_active") == 0
     gpu.configure(N // 2, N, dt, 10, 8, fhi=1000.0)
     assert gpu.get_tuning("hs_bound_active") == 1
+
+
+def test_negative_zero_in_the_plane_counts_as_negative(gpu):
+    """-0.0 written by a host: its upper half (0x8000) is larger, as a 16-bit number, than that of any positive
+    power, so the maximum of its group of four would hide a crossing next to it -- unless the cell raises the
+    'negative power' flag like any other negative value, and every row takes the exact path."""
+    N, dt = 1 << 19, 1e-4
+    fft = synth.noise_fft(N // 2, 91)
+    setup = _configure_with_thresholds(gpu, N // 2, N, dt, 10, 8, [30.0, 40.0, 50.0, 60.0], fhi=2000.0)
+    gpu.load_fft(fft)
+    col = 2 * setup.rlo + 7470 * 3 + 1001
+    res = {}
+    try:
+        for m in (0, 4, 1):
+            gpu.set_tuning("hs_bound", m)
+            gpu.fill_plane()
+            row = gpu.get_plane(4, col - 2, 8)
+            row[2] = np.float32(-0.0)
+            row[3] = np.float32(1000.0)      # a crossing in the same group of four as the -0.0 cell, or the next one
+            row[5] = np.float32(900.0)
+            gpu.put_plane(4, col - 2, row)
+            res[m] = gpu.search_plane(max_hits=1 << 20)
+    finally:
+        gpu.set_tuning("hs_bound", 1)
+    assert len(res[0]) >= 2 and np.any(res[0]["power"] >= 1000.0)
+    _assert_same(res)
+    # the next whole plane generation rewrites every cell a host may have touched: the bounds hold again
+    gpu.set_tuning("hs_bound", 4)
+    try:
+        a = gpu.run(max_hits=1 << 20)
+        assert gpu.get_tuning("pf_listed") >= 0
+        gpu.set_tuning("hs_bound", 0)
+        b = gpu.run(max_hits=1 << 20)
+    finally:
+        gpu.set_tuning("hs_bound", 1)
+    assert a.tobytes() == b.tobytes()
+
+
+def test_coarse_bound_is_left_out_after_it_was_given_up(gpu):
+    """Thresholds so low that the coarse bound's list would be long: a sample taken before the walk says so, the
+    bounded sum runs over the whole plane, and the context goes without the coarse bound for its next launches
+    (4, then 8 ...), trying again after them.  Same hits throughout."""
+    N, dt = 1 << 23, 64e-6
+    fft = synth.noise_fft(N // 2, 92)
+    setup = plan(N // 2, N, dt, 20, 8, fhi=1e9)
+    for s in range(setup.numharmstages):
+        setup.powcut[s] *= 0.6
+    gpu.create_subharminfos(setup.zmax)
+    gpu.set_search(setup)
+    gpu.load_fft(fft)
+    gpu.set_tuning("hits_cap", 1 << 22)
+    gpu.set_tuning("hs_bound", 3)
+    ref = gpu.run(max_hits=1 << 24)
+    gpu.set_tuning("hs_bound", 1)
+    try:
+        seen = []
+        for k in range(7):
+            assert gpu.get_tuning("hs_prefilter_active") == 1 or gpu.get_tuning("pf_skip") >= 0
+            h = gpu.run(max_hits=1 << 24)
+            assert h.tobytes() == ref.tobytes()
+            seen.append((gpu.get_tuning("pf_last_listed"), gpu.get_tuning("pf_skip")))
+        assert seen[0] == (-1, 4), seen                     # given up; the next four go without
+        assert [s[0] for s in seen[1:5]] == [-2] * 4, seen  # ... the coarse bound did not run
+        assert seen[5] == (-1, 8), seen                     # tried again, given up again: eight
+        gpu.set_tuning("pf_memory", 0)                      # every launch tries
+        h = gpu.run(max_hits=1 << 24)
+        assert h.tobytes() == ref.tobytes() and gpu.get_tuning("pf_last_listed") == -1 and gpu.get_tuning("pf_skip") == 0
+        # without the sample the walk runs to the end of its list's room and gives up there: same hits
+        gpu.set_tuning("pf_sample", 0)
+        h = gpu.run(max_hits=1 << 24)
+        assert h.tobytes() == ref.tobytes() and gpu.get_tuning("pf_last_listed") == -1
+    finally:
+        gpu.set_tuning("pf_memory", 1)
+        gpu.set_tuning("pf_sample", 1)
+        gpu.set_tuning("hits_cap", 1 << 20)
+
+
+def test_group_maxima_of_more_blocks_than_a_grid_dimension_counts(gpu):
+    """A series so long that it has more blocks than the 65 535 a launch grid's second dimension can count:
+    the kernel that takes the group maxima from the plane (a host has written into it) folds the blocks into
+    the grid's first dimension.  zmax 0, so that the plane stays small."""
+    numbins = 65600 * 3735 + 4000
+    N, dt = 2 * numbins, 64e-6
+    rng = np.random.default_rng(93)
+    fft = np.empty(numbins, np.complex64)
+    step = 1 << 24
+    for a in range(0, numbins, step):                       # unit-variance complex noise, written in pieces
+        n = min(step, numbins - a)
+        fft[a:a + n] = (rng.standard_normal(n, np.float32) + 1j * rng.standard_normal(n, np.float32)) * np.float32(0.7071)
+    setup = plan(numbins, N, dt, 0, 8, sigma=2.0, flo=1.0, fhi=1e9)
+    for s in range(setup.numharmstages):
+        setup.powcut[s] *= 0.75                               # a handful of noise cells cross
+    gpu.create_subharminfos(setup.zmax)
+    setup = gpu.set_search(setup)
+    assert setup.num_search_blocks + setup.num_prepop_blocks > 65535
+    gpu.load_fft(fft)
+    try:
+        gpu.set_tuning("hs_bound", 3)
+        ref = gpu.run(max_hits=1 << 22)
+        gpu.set_tuning("hs_bound", 4)
+        a = gpu.run(max_hits=1 << 22)                       # maxima from plane generation
+        cell = gpu.get_plane(0, 2 * setup.rlo + 12345, 1)
+        gpu.put_plane(0, 2 * setup.rlo + 12345, cell)       # the same value back: the maxima are taken from the plane now
+        b = gpu.search_plane(max_hits=1 << 22)
+        assert gpu.get_tuning("pf_listed") >= 0
+    finally:
+        gpu.set_tuning("hs_bound", 1)
+    assert len(ref) > 0 and a.tobytes() == ref.tobytes() and b.tobytes() == ref.tobytes()

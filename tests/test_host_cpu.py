@@ -265,3 +265,21 @@ def test_replay_binary_search_equals_the_plain_walk():
         replay_options()
         c1, s1, a1 = replay_candidates(setup, hits[perm])
         assert np.array_equal(c0, c1) and np.array_equal(a0, a1)
+
+
+def test_coarse_bound_shape_predicate():
+    """Where the coarse bound in front of the harmonic sum may run: its kernels count columns in 32 bits, so a
+    plane row of 2^32 columns or more must be refused whatever else holds (forced included); 2 to 16 harmonics
+    on at least 2^22 search columns of 8192-point transforms otherwise."""
+    import presto_amd as pa
+    ok = pa.load_library().accelgpu_coarse_bound_applies
+    cols, rlen = 1 << 23, (1 << 23) + 20000
+    assert ok(5, cols, rlen, 8192, 0) == 1 and ok(2, cols, rlen, 8192, 0) == 1
+    assert ok(1, cols, rlen, 8192, 0) == 0 and ok(1, cols, rlen, 8192, 1) == 0      # nothing to sum
+    assert ok(6, cols, rlen, 8192, 0) == 0 and ok(6, cols, rlen, 8192, 1) == 1      # 32 harmonics: only when forced
+    assert ok(5, (1 << 22) - 1, rlen, 8192, 0) == 0 and ok(5, 1 << 22, rlen, 8192, 0) == 1
+    assert ok(5, cols, rlen, 16384, 0) == 0 and ok(5, cols, rlen, 16384, 1) == 1    # maxima from the plane when forced
+    for forced in (0, 1):
+        assert ok(5, 1 << 33, (1 << 32) - 1, 8192, forced) == 1
+        assert ok(5, 1 << 33, 1 << 32, 8192, forced) == 0
+        assert ok(5, 1 << 33, 1 << 40, 8192, forced) == 0
