@@ -68,6 +68,10 @@ ffdotpows *subharm_ffdot_plane(int numharm, int harmnum, double fullrlo, double 
                                subharminfo *shi, accelobs *obs);
 void fund_to_ffdotplane(ffdotpows *ffd, accelobs *obs);
 void inmem_add_ffdotpows(ffdotpows *fundamental, accelobs *obs, int numharm, int harmnum);
+/* what src/accelsearch.c calls instead with -otheropt (include/accel.h:137-142) */
+void fund_to_ffdotplane_trans(ffdotpows *ffd, accelobs *obs);
+void inmem_add_ffdotpows_trans(ffdotpows *fundamental, accelobs *obs, int numharm, int harmnum);
+void add_ffdotpows_ptrs(ffdotpows *fundamental, ffdotpows *subharmonic, int numharm, int harmnum);
 GSList *search_ffdotpows(ffdotpows *ffdot, int numharm, accelobs *obs, GSList *cands);
 void free_ffdotpows(ffdotpows *ffd);
 void free_accelcand(void *data, void *user_data);

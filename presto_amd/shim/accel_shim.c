@@ -12,6 +12,10 @@
  *   add_ffdotpows         :1119-1134  (standard mode)
  *   search_ffdotpows      :1259-1299  (GPU threshold scan; sigma and the list stay on the host)
  *   free_ffdotpows        :1112-1117
+ *   fund_to_ffdotplane_trans  :1093-1109, inmem_add_ffdotpows_trans  :1211-1256,
+ *   add_ffdotpows_ptrs    :1136-1157  (what accelsearch.c calls instead with -otheropt: the same
+ *                         results from another memory layout or loop form; the plane's layout is
+ *                         invisible behind this seam, so they are the same GPU calls)
  *
  * Errors follow the reference's convention: print, then exit.
  * Build inside PRESTO with its own headers; outside (tests) with
@@ -220,6 +224,26 @@ void inmem_add_ffdotpows(ffdotpows *fundamental, accelobs *obs, int numharm, int
     (void) obs;
     if (accelgpu_inmem_add_ffdotpows(g_ctx, fundamental->powers[0], fundamental->rlo, numharm, harmnum))
         fail("accelgpu_inmem_add_ffdotpows");
+}
+
+/* -otheropt (src/accelsearch.c:154-155, 184-185, 193-195, 204-206): the reference keeps the plane
+ * transposed (r-major) or walks the rows through pointers; the sums are the same numbers.  The plane
+ * here lives in HBM in one layout whatever the caller asks for, so these are the calls above.  Without
+ * them a host linked against this shim would run the reference's own versions on an obs->ffdotplane
+ * that nothing fills. */
+void fund_to_ffdotplane_trans(ffdotpows *ffd, accelobs *obs)
+{
+    fund_to_ffdotplane(ffd, obs);
+}
+
+void inmem_add_ffdotpows_trans(ffdotpows *fundamental, accelobs *obs, int numharm, int harmnum)
+{
+    inmem_add_ffdotpows(fundamental, obs, numharm, harmnum);
+}
+
+void add_ffdotpows_ptrs(ffdotpows *fundamental, ffdotpows *subharmonic, int numharm, int harmnum)
+{
+    add_ffdotpows(fundamental, subharmonic, numharm, harmnum);
 }
 
 #ifdef ACCELGPU_SHIM_STANDALONE

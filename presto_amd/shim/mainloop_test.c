@@ -2,7 +2,8 @@
  * mainloop_test.c -- drives the shim through the same call sequence as the
  * reference's search loop (src/accelsearch.c:116-224, in-memory or standard
  * branch) on a .fft file, and prints the candidate list.  Test program only.
- *   usage: mainloop_test <file.fft> <N> <dt> <zmax> <numharm> <workfile> [inmem=1]
+ *   usage: mainloop_test <file.fft> <N> <dt> <zmax> <numharm> <workfile> [inmem=1] [otheropt=0]
+ *   otheropt = 1 takes the branches of cmd->otheroptP (src/accelsearch.c:154-155, 184-185, 193-195, 204-206).
  */
 #include <math.h>
 #include <stdio.h>
@@ -42,6 +43,8 @@ int main(int argc, char **argv)
     obs.powcut = s.powcut; obs.numindep = (long long *) s.numindep;
     obs.workfile = fopen(argv[6], "w");
 
+    const int otheropt = argc > 8 ? atoi(argv[8]) : 0;
+
     subharminfo **shis = create_subharminfos(&obs);
     GSList *cands = NULL;
     double startr, lastr, nextr;
@@ -50,7 +53,10 @@ int main(int argc, char **argv)
         nextr = startr + ACCEL_USELEN * ACCEL_DR;
         lastr = nextr - ACCEL_DR;
         fund = subharm_ffdot_plane(1, 1, startr, lastr, &shis[0][0], &obs);
-        fund_to_ffdotplane(fund, &obs);
+        if (otheropt)
+            fund_to_ffdotplane_trans(fund, &obs);
+        else
+            fund_to_ffdotplane(fund, &obs);
         free_ffdotpows(fund);
     }
     for (startr = obs.rlo; startr + ACCEL_USELEN * ACCEL_DR < obs.highestbin; startr = nextr) {
@@ -59,17 +65,27 @@ int main(int argc, char **argv)
         fund = subharm_ffdot_plane(1, 1, startr, lastr, &shis[0][0], &obs);
         cands = search_ffdotpows(fund, 1, &obs, cands);
         if (obs.numharmstages > 1) {
-            if (obs.inmem)
-                fund_to_ffdotplane(fund, &obs);
+            if (obs.inmem) {
+                if (otheropt)
+                    fund_to_ffdotplane_trans(fund, &obs);
+                else
+                    fund_to_ffdotplane(fund, &obs);
+            }
             for (int stage = 1; stage < obs.numharmstages; stage++) {
                 const int harmtosum = 1 << stage;
                 for (int harm = 1; harm < harmtosum; harm += 2) {
                     if (obs.inmem) {
-                        inmem_add_ffdotpows(fund, &obs, harmtosum, harm);
+                        if (otheropt)
+                            inmem_add_ffdotpows_trans(fund, &obs, harmtosum, harm);
+                        else
+                            inmem_add_ffdotpows(fund, &obs, harmtosum, harm);
                     } else {
                         ffdotpows *sub = subharm_ffdot_plane(harmtosum, harm, startr, lastr,
                                                              &shis[stage][harm - 1], &obs);
-                        add_ffdotpows(fund, sub, harmtosum, harm);
+                        if (otheropt)
+                            add_ffdotpows_ptrs(fund, sub, harmtosum, harm);
+                        else
+                            add_ffdotpows(fund, sub, harmtosum, harm);
                         free_ffdotpows(sub);
                     }
                 }

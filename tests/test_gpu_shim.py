@@ -192,3 +192,24 @@ def test_command_line_zaplist_on_dat_input(tmp_path):
     assert len(kept) == len(zapped)
     assert [c.numharm for c in zapped] == list(kept["numharm"])
     assert np.allclose([c.r for c in zapped], kept["r"], atol=0.26)
+
+
+@pytest.mark.parametrize("inmem", [1, 0])
+def test_shim_main_loop_otheropt_branches(tmp_path, inmem):
+    """With -otheropt the reference's loop calls fund_to_ffdotplane_trans / inmem_add_ffdotpows_trans /
+    add_ffdotpows_ptrs (src/accelsearch.c:154-155, 184-185, 193-195, 204-206): the same numbers from another
+    layout.  Through the shim they must give exactly the candidates and the work file of the plain calls."""
+    exe = os.path.join(ROOT, "presto_amd", "shim", "mainloop_test")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "-s"])
+    N, dt, zmax, numharm = 1 << 17, 1e-3, 20, 8
+    fft = synth.make_fft(N, dt, [dict(f=37.3, z=7.0, amp=0.35, duty=0.05)], seed=5)
+    root = str(tmp_path / "shimopt")
+    synth.write_fft(root, fft, N, dt)
+    outs, works = [], []
+    for otheropt in (0, 1):
+        out = subprocess.check_output([exe, root + ".fft", str(N), repr(dt), str(zmax), str(numharm),
+                                       root + ".txtcand", str(inmem), str(otheropt)], timeout=170).decode()
+        outs.append([l for l in out.splitlines() if l.startswith("CAND")])
+        works.append(open(root + ".txtcand").read())
+    assert len(outs[0]) > 0 and outs[0] == outs[1] and works[0] == works[1]
