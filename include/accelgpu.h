@@ -255,14 +255,22 @@ int accelgpu_set_search(accelgpu_ctx *ctx, const accelgpu_setup *setup, int norm
  * blocks [first_block, first_block + num_blocks) of the reference grid.  The
  * following fill generates only the plane blocks those columns and their
  * sub-harmonic look-ups (columns (int)(rind*h/n + 0.5), src/accel_utils.c:1174)
- * fall in -- recomputed locally instead of exchanged -- and the search covers
- * only those columns; hit block indices stay global.  *blocks_generated
+ * fall in -- recomputed locally instead of exchanged; of blocks outside the range only the z
+ * rows those look-ups can reach -- and the search covers only those columns; hit block
+ * indices stay global.  *blocks_generated
  * (optional) receives the number of plane blocks a fill will compute.
  * accelgpu_set_search() resets the range to all blocks.
  * ref: the loop bounds of src/accelsearch.c:165-168 (the reference has no
  * counterpart; it searches the whole range in one process). */
 int accelgpu_set_block_range(accelgpu_ctx *ctx, int32_t first_block, int32_t num_blocks,
                              int32_t *blocks_generated);
+/* The same question without a GPU, for whoever divides the blocks among ranks: the plane blocks
+ * a fill would compute for that range and the (block, z row)s in them -- of a block that only
+ * serves as a source, a harmonic h/n reaches the rows |z| <= h/n * zmax alone, and only those
+ * are generated.  `setup` as accelgpu_plan() returns it.
+ * ref: none (see accelgpu_set_block_range). */
+int accelgpu_block_range_need(const accelgpu_setup *setup, int32_t first_block, int32_t num_blocks,
+                              int32_t *blocks_generated, int64_t *rows_generated);
 
 /* Generates the whole fundamental plane: every pre-population block and every
  * search block of the reference grid (startr = 8 + k*3735 below rlo,

@@ -71,6 +71,7 @@ def load_library():
     L.accelgpu_z_resp_halfwidth.argtypes = [d]
     L.accelgpu_calc_fftlen.argtypes = [i, i, i]
     L.accelgpu_coarse_bound_applies.argtypes = [i, i64, i64, i, i]
+    L.accelgpu_block_range_need.argtypes = [pS, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     L.accelgpu_candidate_sigma.argtypes = [d, i, d]; L.accelgpu_candidate_sigma.restype = d
     L.accelgpu_power_for_sigma.argtypes = [d, i, d]; L.accelgpu_power_for_sigma.restype = d
     L.accelgpu_plan.argtypes = [i64, i64, d, i, i, d, d, d, i64, pS]
@@ -221,6 +222,15 @@ def replay_options(linear_walk=False, threads=-1):
     """How replay_candidates() works (never what it returns): the reference's plain list
     walk instead of the binary search; a fixed number of sigma threads."""
     _check(load_library().accelgpu_replay_options(int(bool(linear_walk)), int(threads)))
+
+
+def block_range_need(setup, first_block, num_blocks):
+    """(plane blocks, (block, z row)s) a rank that searches the search blocks [first, first + n) of `setup`
+    has to generate.  Host arithmetic only."""
+    L = load_library()
+    nb, rows = C.c_int32(0), C.c_int64(0)
+    _check(L.accelgpu_block_range_need(C.byref(setup), int(first_block), int(num_blocks), C.byref(nb), C.byref(rows)))
+    return nb.value, rows.value
 
 
 def replay_candidates(setup, hits):

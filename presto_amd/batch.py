@@ -5,8 +5,9 @@ The search shards without any data-path collective:
     (the reference runs one accelsearch process per file,
     bin/GBNCC_search.py:360-413);
   * one long series: contiguous ranges of the reference's search blocks
-    (startr = rlo + k*3735, src/accelsearch.c:165-218); a rank regenerates the
-    plane blocks its sub-harmonic look-ups fall in instead of receiving them.
+    (startr = rlo + k*3735, src/accelsearch.c:165-218), cut so that the ranks have
+    equal work; a rank regenerates the plane rows its sub-harmonic look-ups fall
+    in instead of receiving them.
 The only exchange is an all-gather of fixed-size candidate records (RCCL over
 xGMI when the tensors live on GPUs, gloo on CPU for tests).
 """
@@ -29,6 +30,60 @@ def split_blocks(nblocks, world):
         out.append((first, first + n))
         first += n
     return out
+
+
+# What a (block, z row) costs a rank: generating it (one inverse transform) against summing and thresholding its
+# cells, as measured on one MI355X for a 2^27-point, zmax 300, 16-harmonic search (69.3 ms of plane generation over
+# 17 968 x 301 rows, 32.6 ms of harmonic sum over 17 965 x 301).
+GEN_COST, SUM_COST = 69.3 / (17968 * 301), 32.6 / (17965 * 301)
+
+
+def range_cost(setup, first, n, need=None):
+    """Predicted milliseconds of a rank that searches the search blocks [first, first + n): the rows it generates
+    (its own blocks whole; of the blocks its sub-harmonic look-ups fall in, the rows those reach) and the rows it sums."""
+    if need is None:
+        from .api import block_range_need as need
+    if n <= 0:
+        return 0.0
+    _, rows = need(setup, first, n)
+    return GEN_COST * rows + SUM_COST * n * setup.numz
+
+
+def split_blocks_by_cost(setup, world, need=None):
+    """Contiguous [first, last) ranges of search blocks, one per rank, so that every rank has about the same
+    WORK -- not the same number of searched blocks: a rank high up the spectrum regenerates most of the plane
+    below it (every harmonic h/n of its columns, at rows |z| <= h/n zmax), a rank at the bottom next to nothing.
+    The smallest bound T such that cutting greedily from the bottom, each range as long as it costs at most T,
+    reaches the top with `world` ranges."""
+    nb = setup.num_search_blocks
+    cost = lambda a, n: range_cost(setup, a, n, need)
+
+    def cut(T):
+        out, first = [], 0
+        for _ in range(world):
+            lo, hi = 0, nb - first                     # the longest n with cost(first, n) <= T (cost grows with n)
+            while lo < hi:
+                mid = (lo + hi + 1) // 2
+                if cost(first, mid) <= T:
+                    lo = mid
+                else:
+                    hi = mid - 1
+            out.append((first, first + lo))
+            first += lo
+        return out, first
+
+    lo_t, hi_t = 0.0, cost(0, nb)
+    for _ in range(40):
+        mid = 0.5 * (lo_t + hi_t)
+        if cut(mid)[1] >= nb:
+            hi_t = mid
+        else:
+            lo_t = mid
+        if hi_t - lo_t <= 1e-3 * hi_t:
+            break
+    ranges, reached = cut(hi_t)
+    assert reached >= nb
+    return ranges
 
 
 def cands_to_records(trial, cands):
@@ -112,7 +167,7 @@ def search_long_series(gpu, rank, world, max_hits=1 << 22, gather=None):
     hits are all-gathered and put back into the reference's order so that the
     candidate list can be replayed exactly as a single process would.
     `gather(records) -> records` defaults to the torch.distributed all-gather."""
-    first, last = split_blocks(gpu.setup.num_search_blocks, world)[rank]
+    first, last = split_blocks_by_cost(gpu.setup, world)[rank]
     gpu.set_block_range(first, last - first)
     hits = gpu.run(max_hits)
     rec = hits_to_records(hits)

@@ -289,6 +289,100 @@ struct Entry {
 static std::atomic<bool> g_replay_linear{false};
 static std::atomic<int> g_replay_threads{-1};
 
+void block_grid(double rlo, int64_t highestbin, int halfwidth, BlockGrid *g)
+{
+    *g = BlockGrid();
+    const double step = ACCELGPU_USELEN * 0.5;
+    auto describe = [&](double startr, int64_t *lobin, int *brlo, int *numdata) {
+        const double fullrhi = startr + ACCELGPU_USELEN * 0.5 - 0.5;
+        const double drlo = calc_required_r(1.0, startr), drhi = calc_required_r(1.0, fullrhi);
+        *brlo = (int) std::floor(drlo);
+        *lobin = (int64_t) *brlo - halfwidth;
+        const int hibin = (int) std::ceil(drhi) + halfwidth;
+        *numdata = (int) (hibin - *lobin + 1);
+    };
+    g->search_col0 = (int64_t) std::floor(calc_required_r(1.0, rlo)) * 2;
+    auto add = [&](double r, bool prepop) {
+        int64_t lobin;
+        int brlo, numdata;
+        describe(r, &lobin, &brlo, &numdata);
+        g->lobin.push_back(lobin);
+        g->rlo.push_back(brlo);
+        g->numdata.push_back(numdata);
+        g->col.push_back((int64_t) brlo * 2);
+        // columns at or above the first search column belong to the search blocks
+        g->ncols.push_back(prepop ? (int) std::max<int64_t>(0, std::min<int64_t>(ACCELGPU_USELEN, g->search_col0 - (int64_t) brlo * 2))
+                                  : ACCELGPU_USELEN);
+    };
+    for (double r = 8; r < rlo; r += step) {
+        add(r, true);
+        g->nprepop++;
+    }
+    for (double r = rlo; r + step < (double) highestbin; r += step) {
+        add(r, false);
+        g->nsearch++;
+    }
+}
+
+int block_range_need(const accelgpu_setup *s, const BlockGrid &g, int first, int n, std::vector<int> *z0, std::vector<int> *z1,
+                     int64_t *rows_generated)
+{
+    const int nblk = g.nprepop + g.nsearch, numz = s->numz;
+    z0->assign((size_t) nblk, 0);
+    z1->assign((size_t) nblk, 0);
+    auto want = [&](int b, int lo, int hi) { // rows [lo, hi) of block b as well
+        if ((*z1)[b] == 0) {
+            (*z0)[b] = lo;
+            (*z1)[b] = hi;
+        } else {
+            (*z0)[b] = std::min((*z0)[b], lo);
+            (*z1)[b] = std::max((*z1)[b], hi);
+        }
+    };
+    if (n > 0) {
+        for (int k = 0; k < n; k++)
+            want(g.nprepop + first + k, 0, numz);
+        const int64_t ca = g.search_col0 + (int64_t) first * ACCELGPU_USELEN;
+        const int64_t cb = ca + (int64_t) n * ACCELGPU_USELEN - 1;
+        // the block a plane column lies in: pre-population blocks are USELEN columns apart from their first
+        // column on, search blocks from search_col0 on; columns below the first block belong to none
+        auto block_of = [&](int64_t c) -> int {
+            if (c >= g.search_col0)
+                return g.nprepop + (int) std::min<int64_t>((c - g.search_col0) / ACCELGPU_USELEN, g.nsearch - 1);
+            if (g.nprepop == 0 || c < g.col[0])
+                return -1;
+            return (int) std::min<int64_t>((c - g.col[0]) / ACCELGPU_USELEN, g.nprepop - 1);
+        };
+        for (int st = 1; st < s->numharmstages; st++)
+            for (int h = 1; h < (1 << st); h += 2) {
+                const double f = (double) h / (double) (1 << st);
+                const int64_t lo = (ca * h + (1 << (st - 1))) >> st, hi = (cb * h + (1 << (st - 1))) >> st;
+                // source rows: monotonic in z, so the ends give the range
+                const int ra = index_from_z(calc_required_z(f, s->zlo), s->zlo);
+                const int rb = index_from_z(calc_required_z(f, s->zlo + 2.0 * (numz - 1)), s->zlo);
+                const int rlo = std::min(ra, rb), rhi = std::max(ra, rb) + 1;
+                int b0 = block_of(lo);
+                const int b1 = block_of(hi);
+                if (b1 < 0)
+                    continue; // below every block: cells nothing writes (they read as zero)
+                b0 = std::max(b0 - 1, 0); // (a block either side: the test below is the exact one)
+                for (int b = b0; b <= std::min(b1 + 1, nblk - 1); b++)
+                    if (g.ncols[b] > 0 && g.col[b] <= hi && g.col[b] + g.ncols[b] - 1 >= lo)
+                        want(b, rlo, rhi);
+            }
+    }
+    int blocks = 0;
+    int64_t rows = 0;
+    for (int b = 0; b < nblk; b++)
+        if ((*z1)[b] > (*z0)[b]) {
+            blocks++;
+            rows += (*z1)[b] - (*z0)[b];
+        }
+    if (rows_generated)
+        *rows_generated = rows;
+    return blocks;
+}
+
 void replay_options(int linear_walk, int threads)
 {
     g_replay_linear.store(linear_walk != 0);

@@ -213,8 +213,10 @@ __global__ __launch_bounds__(P::NT) void k_block_prep(
     const c32 *__restrict__ fft, int64_t numbins, int64_t file_lobin,
     const int64_t *__restrict__ blk_lobin, const int *__restrict__ blk_numdata,
     c32 *__restrict__ blockfft, double nph_norm, int locpow, const int *__restrict__ blk_nice,
-    const c32 *__restrict__ tw1, const c32 *__restrict__ tw2)
+    const c32 *__restrict__ tw1, const c32 *__restrict__ tw2, const int2 *__restrict__ zrange = nullptr)
 {
+    if (zrange && zrange[blockIdx.x].y <= zrange[blockIdx.x].x)
+        return; // a series split over several GPUs: no row of this block is wanted here
     extern __shared__ __attribute__((aligned(16))) char smem[];
     c32 *lds = reinterpret_cast<c32 *>(smem);
     // wave partial counts live behind the FFT image (launch with LDS_BYTES + 64)
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
     float *__restrict__ plane, int64_t rlen, int halfwidth, const c32 *__restrict__ pw1,
     const c32 *__restrict__ pw2, int numz, int tile_z, int tile_c, Stamp stamp = Stamp(),
     unsigned short *__restrict__ hi = nullptr, unsigned short *__restrict__ lo = nullptr,
-    unsigned short *__restrict__ mx = nullptr, int64_t mxlen = 0)
+    unsigned short *__restrict__ mx = nullptr, int64_t mxlen = 0, const int2 *__restrict__ zrange = nullptr)
 {
     static_assert(!MAXIMA || (PAIR && SPLIT && ZL), "group maxima come with the paired stores into split planes");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -626,8 +628,17 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
         ia = blockIdx.x;
         cy = blockIdx.y;
     }
-    const int b0 = cy * chunk;
-    const int b1 = min(b0 + chunk, nitems);
+    int b0 = cy * chunk;
+    int b1 = min(b0 + chunk, nitems);
+    if constexpr (ZL) {
+        // a series split over several GPUs: of a block that only serves as a source of sub-harmonic look-ups,
+        // only the rows those can reach are wanted (zrange[block] = [first row, one past the last))
+        if (zrange) {
+            const int2 zr = zrange[ia];
+            b0 = max(b0, zr.x);
+            b1 = min(b1, zr.y);
+        }
+    }
     if (b0 >= b1)
         return;
     const int z = ZL ? b0 : ia; // ZL: the first template of the chunk
@@ -1620,7 +1631,7 @@ __global__ __launch_bounds__(256) void k_prefilter_lanes(
     const unsigned short *__restrict__ mx, int numz, GroupGrid g, int64_t ngroups,
     const int64_t *__restrict__ rowmx /*[numz][NHS] byte offsets of the source rows in the plane of maxima*/,
     const uint32_t *__restrict__ rowchg, HarmParams prm, WorkItem *__restrict__ work, unsigned int *__restrict__ ctl,
-    unsigned int limit, int xcd_remap, const unsigned int *__restrict__ flags)
+    unsigned int limit, int xcd_remap, const unsigned int *__restrict__ flags, uint32_t group0)
 {
     constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
     __shared__ PfShared sh;
@@ -1639,9 +1650,11 @@ __global__ __launch_bounds__(256) void k_prefilter_lanes(
     }
     if (!pf_begin(sh, ctl))
         return; // given up before this workgroup started
+    // the lane's group among the `ngroups` walked, which begin with group0 of the search region (a context that
+    // searches a range of blocks only)
     const int64_t gid = (int64_t) tile * 256 + threadIdx.x;
     const bool live = gid < ngroups;
-    const uint32_t gl = live ? (uint32_t) gid : 0u;
+    const uint32_t gl = group0 + (live ? (uint32_t) gid : 0u);
     // the group's columns within the search region
     const uint32_t sb = gl / (uint32_t) kGpb;
     const int lg = (int) (gl % (uint32_t) kGpb);
@@ -1725,7 +1738,7 @@ __global__ __launch_bounds__(256) void k_prefilter_lanes(
         any = any && live;
         const unsigned long long mask = __ballot(any);
         if (mask)
-            pf_insert(sh, mask, any, lane, WorkItem{(uint32_t) zi, (uint32_t) gid}, work, ctl, limit);
+            pf_insert(sh, mask, any, lane, WorkItem{(uint32_t) zi, gl}, work, ctl, limit);
     }
     __syncthreads();
     pf_flush(sh, work, ctl, limit);
@@ -1769,7 +1782,7 @@ __global__ __launch_bounds__(256) void k_prefilter_pairs(
     const unsigned short *__restrict__ mx, int numz, GroupGrid g, int64_t ngroups,
     const int64_t *__restrict__ rowmx /*[numz][NHS] byte offsets of the source rows in the plane of maxima*/,
     const uint32_t *__restrict__ rowchg, HarmParams prm, WorkItem *__restrict__ work, unsigned int *__restrict__ ctl,
-    unsigned int limit, int xcd_remap, const unsigned int *__restrict__ flags)
+    unsigned int limit, int xcd_remap, const unsigned int *__restrict__ flags, uint32_t group0)
 {
     constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
     __shared__ PfShared sh;
@@ -1791,7 +1804,7 @@ __global__ __launch_bounds__(256) void k_prefilter_pairs(
         return; // given up before this workgroup started
     const int64_t pid = (int64_t) tile * 256 + threadIdx.x;
     const bool live = pid < npairs;
-    const uint32_t gidA = live ? (uint32_t) NG * (uint32_t) pid : 0u; // the first of the lane's groups
+    const uint32_t gidA = group0 + (live ? (uint32_t) NG * (uint32_t) pid : 0u); // the first of the lane's groups (group0: even)
     const uint32_t sb = gidA / (uint32_t) kGpb;
     const int lgA = (int) (gidA % (uint32_t) kGpb);
     uint32_t cf[NG], cl[NG];
@@ -1879,7 +1892,7 @@ __global__ __launch_bounds__(256) void k_prefilter_pairs(
         for (int k = 0; k < NG; k++) {
             const unsigned long long mask = crossing[k];
             if (mask)
-                pf_insert(sh, mask, (mask >> lane) & 1ull, lane, WorkItem{(uint32_t) zi, (uint32_t) NG * (uint32_t) pid + (uint32_t) k},
+                pf_insert(sh, mask, (mask >> lane) & 1ull, lane, WorkItem{(uint32_t) zi, gidA + (uint32_t) k},
                           work, ctl, limit);
         }
     }
@@ -1896,7 +1909,7 @@ template <int NSTAGES>
 __global__ __launch_bounds__(256) void k_prefilter_sample(
     const unsigned short *__restrict__ mx, int numz, GroupGrid g, int64_t ngroups, const int64_t *__restrict__ rowmx,
     HarmParams prm, unsigned int *__restrict__ ctl, unsigned int nsamples, unsigned int gstep, unsigned int sample_limit,
-    const unsigned int *__restrict__ flags)
+    const unsigned int *__restrict__ flags, uint32_t group0)
 {
     constexpr int NHS = HarmShape<NSTAGES>::NHS;
     __shared__ unsigned int found;
@@ -1910,7 +1923,7 @@ __global__ __launch_bounds__(256) void k_prefilter_sample(
     __syncthreads();
     const unsigned int k = blockIdx.x * 256 + threadIdx.x;
     const bool live = k < nsamples;
-    const uint32_t gl = (uint32_t) (((uint64_t) (live ? k : 0u) * gstep) % (uint64_t) ngroups);
+    const uint32_t gl = group0 + (uint32_t) (((uint64_t) (live ? k : 0u) * gstep) % (uint64_t) ngroups);
     const int zi = (int) ((((live ? k : 0u) * 2654435761u) >> 8) % (uint32_t) numz);
     const uint32_t sb = gl / (uint32_t) kGpb;
     const int lg = (int) (gl % (uint32_t) kGpb);

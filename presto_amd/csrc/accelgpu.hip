@@ -177,9 +177,12 @@ struct accelgpu_ctx {
     float nph = 0.f;
     int nblk = 0, nprepop = 0, nsearch = 0;
     int nblk_active = 0;      // blocks generated by fill (all of them unless a block range is set)
+    bool partial_fill = false; // a block range is set: a fill generates some blocks, or some rows of them, only
     int range_first = 0, range_count = 0; // search blocks this context searches
     std::vector<int64_t> h_blk_lobin, h_blk_col; // host copies of the full block grid
     std::vector<int> h_blk_numdata, h_blk_ncols;
+    accelhost::BlockGrid grid_host;
+    int2 *d_blk_zrange = nullptr; // per generated block: the z rows [x, y) a fill computes (a block range is set)
     int64_t col0 = 0, ncols = 0; // first search column (2*rlo) and number of search columns
     int64_t *d_blk_lobin = nullptr, *d_blk_col = nullptr;
     int *d_blk_numdata = nullptr, *d_blk_ncols = nullptr;
@@ -515,7 +518,7 @@ BlockDesc describe_block(double startr, int halfwidth)
 }
 
 int launch_block_prep(accelgpu_ctx *ctx, int nblk, const int64_t *d_lobin, const int *d_numdata,
-                      c32 *d_out)
+                      c32 *d_out, const int2 *d_zrange = nullptr)
 {
     const double nph_norm = ctx->nph > 0.f ? 1.0 / std::sqrt((double) ctx->nph) : 0.0;
     EventPair ep;
@@ -526,13 +529,13 @@ int launch_block_prep(accelgpu_ctx *ctx, int nblk, const int64_t *d_lobin, const
                            P4K::LDS_BYTES + 64, ctx->stream, ctx->d_fft, ctx->numbins,
                            ctx->setup.lobin, d_lobin, d_numdata, d_out, nph_norm,
                            ctx->norm_type == 1 ? 1 : 0, (const int *) nullptr,
-                           ctx->tw_fwd_half.tw1, ctx->tw_fwd_half.tw2);
+                           ctx->tw_fwd_half.tw1, ctx->tw_fwd_half.tw2, d_zrange);
     } else {
         hipLaunchKernelGGL(accelk::k_block_prep<P8K>, dim3(nblk), dim3(P8K::NT),
                            P8K::LDS_BYTES + 64, ctx->stream, ctx->d_fft, ctx->numbins,
                            ctx->setup.lobin, d_lobin, d_numdata, d_out, nph_norm,
                            ctx->norm_type == 1 ? 1 : 0, (const int *) nullptr,
-                           ctx->tw_fwd_half.tw1, ctx->tw_fwd_half.tw2);
+                           ctx->tw_fwd_half.tw1, ctx->tw_fwd_half.tw2, d_zrange);
     }
     HIPCHK(hipGetLastError());
     return prof_end(ctx, 0, &ep);
@@ -570,13 +573,14 @@ dim3 corr_grid(const Tuning &tn, int numz, int nchunks, int *tile_z, int *tile_c
 // 16-bit halves (register form looping over templates only; see k_harmsum_b).
 int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const int64_t *d_col,
                      const int *d_ncols, float *d_plane, int64_t rlen, unsigned short *d_hi = nullptr,
-                     unsigned short *d_lo = nullptr, unsigned short *d_mx = nullptr, int64_t mxlen = 0)
+                     unsigned short *d_lo = nullptr, unsigned short *d_mx = nullptr, int64_t mxlen = 0,
+                     const int2 *d_zrange = nullptr)
 {
     // Register-resident twiddle form for both plans (measured on one device: 3.3 against
     // 5.8 ms per 2^23-point zmax 200 search, 83 against 116 ms per 2^24-point zmax 1200
     // search).  Tuning corr_rr = 0 selects the table form for A/B runs.
     const Tuning &tn = ctx->tune;
-    const bool rr = tn.corr_rr != 0 || d_hi; // (only the register form writes split planes)
+    const bool rr = tn.corr_rr != 0 || d_hi || d_zrange; // (only the register form writes split planes and takes row ranges)
     int chunk = corr_chunk(rr ? 16 : 8, ctx->numz, nblk);   // blocks per workgroup (templates in the ZL form)
     if (tn.corr_chunk > 0)
         chunk = tn.corr_chunk;
@@ -592,7 +596,7 @@ int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const i
     // block's spectrum stays in registers: a third less L2->L1 traffic per transform than
     // one template looping over blocks; 2.67 against 2.78 ms on a 201 x 1123 grid, chunks
     // of 16 templates against 8: 2.75, 32: 2.81).  Tuning corr_zl = 0 selects the other loop.
-    const bool zl = tn.corr_zl != 0 || d_hi;
+    const bool zl = tn.corr_zl != 0 || d_hi || d_zrange; // (row ranges per block: only the template loop knows them)
     int tile_z = 0, tile_c = 0;
     dim3 rgrid;
     if (zl) {
@@ -607,7 +611,7 @@ int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const i
     hipLaunchKernelGGL((accelk::k_correlate_rr<PLAN, false, 16, ZL, afft::NoStamp, SPLIT, PAIR>), rgrid, dim3(PLAN::NT),   \
                        PLAN::LDS_BYTES + std::min(std::max(tn.corr_lds, 0), 20000), ctx->stream, ctx->d_bank, d_blockfft, d_col, d_ncols,   \
                        nblk, chunk, d_plane, rlen, ctx->halfwidth, ctx->pw_inv.pw1,            \
-                       ctx->pw_inv.pw2, ctx->numz, tile_z, tile_c, afft::NoStamp(), d_hi, d_lo, (unsigned short *) nullptr, (int64_t) 0)
+                       ctx->pw_inv.pw2, ctx->numz, tile_z, tile_c, afft::NoStamp(), d_hi, d_lo, (unsigned short *) nullptr, (int64_t) 0, zl ? d_zrange : nullptr)
     // 8192 points, loop over templates: the last pass hands a thread adjacent outputs, stored two
     // at a time (corr_pair = 0: one at a time, for comparisons; the powers are the same bits)
     const bool pair = tn.corr_pair != 0;
@@ -616,7 +620,7 @@ int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const i
         hipLaunchKernelGGL((accelk::k_correlate_rr<P8K, false, 16, true, afft::NoStamp, true, true, true>), rgrid, dim3(P8K::NT),
                            P8K::LDS_BYTES + std::min(std::max(tn.corr_lds, 0), 20000), ctx->stream, ctx->d_bank, d_blockfft, d_col,
                            d_ncols, nblk, chunk, d_plane, rlen, ctx->halfwidth, ctx->pw_inv.pw1, ctx->pw_inv.pw2, ctx->numz,
-                           tile_z, tile_c, afft::NoStamp(), d_hi, d_lo, d_mx, mxlen);
+                           tile_z, tile_c, afft::NoStamp(), d_hi, d_lo, d_mx, mxlen, d_zrange);
     } else if (rr && zl && ctx->fftlen == 8192 && pair) {
         if (d_hi) LAUNCH_RR(P8K, true, true, true);
         else LAUNCH_RR(P8K, true, false, true);
@@ -788,7 +792,7 @@ bool prefilter_wanted(const accelgpu_ctx *ctx)
 }
 bool maxima_from_plane_generation(const accelgpu_ctx *ctx)
 {
-    return prefilter_wanted(ctx) && ctx->fftlen == 8192 && ctx->tune.corr_pair != 0 && ctx->nblk_active == ctx->nblk;
+    return prefilter_wanted(ctx) && ctx->fftlen == 8192 && ctx->tune.corr_pair != 0;
 }
 
 int launch_prefilter(accelgpu_ctx *ctx, int nstages, const accelk::HarmParams &prm, const HitTarget &out, unsigned int cap,
@@ -810,7 +814,8 @@ int launch_prefilter(accelgpu_ctx *ctx, int nstages, const accelk::HarmParams &p
                            ctx->stream, ctx->d_mx, g, ctx->numz);
         ctx->mx_fix_pending = false;
     }
-    const int64_t ngroups = (int64_t) ctx->nsearch * accelk::kGpb;
+    const int64_t ngroups = (int64_t) ctx->range_count * accelk::kGpb; // of the blocks this context searches
+    const uint32_t group0 = (uint32_t) ctx->range_first * (uint32_t) accelk::kGpb;
     // One 8-byte load per source (k_prefilter_pairs): with up to 8 harmonics a lane takes two adjacent groups (a
     // quarter of the load instructions: 0.69 against 0.95 ms on a 2^23-point, zmax 200 plane).  With 16 harmonics
     // its registers leave five waves per SIMD: 1.71 ms with two groups per lane, 2.28 with one, against 1.72 ms
@@ -838,16 +843,16 @@ int launch_prefilter(accelgpu_ctx *ctx, int nstages, const accelk::HarmParams &p
     do {                                                                                                       \
         if (ctx->tune.pf_sample)                                                                               \
             hipLaunchKernelGGL((accelk::k_prefilter_sample<NS>), dim3((nsamples + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_mx, \
-                               ctx->numz, g, ngroups, ctx->d_rowmx, prm, ctx->d_ctl, nsamples, gstep, sample_limit, ctx->d_flags); \
+                               ctx->numz, g, ngroups, ctx->d_rowmx, prm, ctx->d_ctl, nsamples, gstep, sample_limit, ctx->d_flags, group0); \
         if (per_lane == 2)                                                                                     \
             hipLaunchKernelGGL((accelk::k_prefilter_pairs<(NS > 5 ? 5 : NS), 2>), dim3(nt), dim3(256), 0, ctx->stream, ctx->d_mx, ctx->numz, g, \
-                               ngroups, ctx->d_rowmx, ctx->d_rowchg, prm, ctx->d_work, ctx->d_ctl, wcap, remap, ctx->d_flags); \
+                               ngroups, ctx->d_rowmx, ctx->d_rowchg, prm, ctx->d_work, ctx->d_ctl, wcap, remap, ctx->d_flags, group0); \
         else if (per_lane == 1)                                                                                \
             hipLaunchKernelGGL((accelk::k_prefilter_pairs<(NS > 5 ? 5 : NS), 1>), dim3(nt), dim3(256), 0, ctx->stream, ctx->d_mx, ctx->numz, g, \
-                               ngroups, ctx->d_rowmx, ctx->d_rowchg, prm, ctx->d_work, ctx->d_ctl, wcap, remap, ctx->d_flags); \
+                               ngroups, ctx->d_rowmx, ctx->d_rowchg, prm, ctx->d_work, ctx->d_ctl, wcap, remap, ctx->d_flags, group0); \
         else                                                                                                   \
             hipLaunchKernelGGL((accelk::k_prefilter_lanes<NS>), dim3(nt), dim3(256), 0, ctx->stream, ctx->d_mx, ctx->numz, g, \
-                               ngroups, ctx->d_rowmx, ctx->d_rowchg, prm, ctx->d_work, ctx->d_ctl, wcap, remap, ctx->d_flags); \
+                               ngroups, ctx->d_rowmx, ctx->d_rowchg, prm, ctx->d_work, ctx->d_ctl, wcap, remap, ctx->d_flags, group0); \
         hipLaunchKernelGGL((accelk::k_flagged_exact<NS>), dim3(4096), dim3(256), 0, ctx->stream, ctx->d_hi, ctx->d_lo,       \
                            ctx->setup.rlen, g, ctx->d_rowhalf, prm, ctx->d_work, ctx->d_ctl, wcap, out.hits, out.count, cap); \
     } while (0)
@@ -915,7 +920,8 @@ int launch_harmsum(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, 
             // (row, group)s that could cross listed and summed exactly; the plain bounded sum below then
             // runs only if the list was of no use (its workgroups return at once otherwise).
             const unsigned int *gate = nullptr;
-            if (prefilter_wanted(ctx) && ctx->nblk_active == ctx->nblk && col0 == ctx->col0 && ncols == ctx->ncols) {
+            if (prefilter_wanted(ctx) && col0 == ctx->col0 + (int64_t) ctx->range_first * ACCELGPU_USELEN &&
+                ncols == (int64_t) ctx->range_count * ACCELGPU_USELEN) { // the columns this context searches
                 int rc = launch_prefilter(ctx, nstages, prm, out, cap, remap);
                 if (rc) return rc;
                 gate = ctx->d_ctl;
@@ -1102,26 +1108,26 @@ int queue_fill(accelgpu_ctx *ctx)
 {
     if (ctx->nblk_active == 0)
         return ACCELGPU_OK;
-    int rc = launch_block_prep(ctx, ctx->nblk_active, ctx->d_blk_lobin, ctx->d_blk_numdata,
-                               ctx->d_blockfft);
+    const int2 *zrange = ctx->partial_fill ? ctx->d_blk_zrange : nullptr;
+    int rc = launch_block_prep(ctx, ctx->nblk, ctx->d_blk_lobin, ctx->d_blk_numdata, ctx->d_blockfft, zrange);
     if (rc) return rc;
     ctx->mx_valid = false;
     if (bounds_in_use(ctx)) {
         // every cell a host may have written a negative power into is rewritten now: the bounds hold again
-        if (ctx->nblk_active == ctx->nblk && !ctx->host_wrote_outside)
+        if (!ctx->partial_fill && !ctx->host_wrote_outside)
             HIPCHK(hipMemsetAsync(ctx->d_flags, 0, 64, ctx->stream));
         if (maxima_from_plane_generation(ctx)) {
             if ((rc = ensure_prefilter(ctx))) return rc;
-            rc = launch_correlate(ctx, ctx->nblk_active, ctx->d_blockfft, ctx->d_blk_col, ctx->d_blk_ncols, nullptr,
-                                  ctx->setup.rlen, ctx->d_hi, ctx->d_lo, ctx->d_mx, ctx->grid.mxlen);
+            rc = launch_correlate(ctx, ctx->nblk, ctx->d_blockfft, ctx->d_blk_col, ctx->d_blk_ncols, nullptr,
+                                  ctx->setup.rlen, ctx->d_hi, ctx->d_lo, ctx->d_mx, ctx->grid.mxlen, zrange);
             ctx->mx_valid = ctx->mx_fix_pending = rc == ACCELGPU_OK;
             return rc;
         }
-        return launch_correlate(ctx, ctx->nblk_active, ctx->d_blockfft, ctx->d_blk_col, ctx->d_blk_ncols, nullptr,
-                                ctx->setup.rlen, ctx->d_hi, ctx->d_lo);
+        return launch_correlate(ctx, ctx->nblk, ctx->d_blockfft, ctx->d_blk_col, ctx->d_blk_ncols, nullptr,
+                                ctx->setup.rlen, ctx->d_hi, ctx->d_lo, nullptr, 0, zrange);
     }
-    return launch_correlate(ctx, ctx->nblk_active, ctx->d_blockfft, ctx->d_blk_col, ctx->d_blk_ncols,
-                            ctx->d_plane, ctx->setup.rlen);
+    return launch_correlate(ctx, ctx->nblk, ctx->d_blockfft, ctx->d_blk_col, ctx->d_blk_ncols,
+                            ctx->d_plane, ctx->setup.rlen, nullptr, nullptr, nullptr, 0, zrange);
 }
 
 // Plane generation and harmonic sum of one whole trial, chunk by chunk in ascending r: the
@@ -1402,6 +1408,22 @@ int accelgpu_coarse_bound_applies(int numharmstages, int64_t search_columns, int
 {
     return coarse_bound_shape_ok(numharmstages, search_columns, rlen, fftlen, forced != 0) ? 1 : 0;
 }
+int accelgpu_block_range_need(const accelgpu_setup *setup, int32_t first_block, int32_t num_blocks, int32_t *blocks_generated,
+                              int64_t *rows_generated)
+{
+    if (!setup || first_block < 0 || num_blocks < 0 || first_block + num_blocks > setup->num_search_blocks) {
+        set_error("accelgpu_block_range_need: null set-up or a range outside its search blocks");
+        return ACCELGPU_ERR_ARG;
+    }
+    accelhost::BlockGrid g;
+    accelhost::block_grid(setup->rlo, setup->highestbin, setup->halfwidth, &g);
+    std::vector<int> z0, z1;
+    int64_t rows = 0;
+    const int nb = accelhost::block_range_need(setup, g, first_block, num_blocks, &z0, &z1, &rows);
+    if (blocks_generated) *blocks_generated = nb;
+    if (rows_generated) *rows_generated = rows;
+    return ACCELGPU_OK;
+}
 int accelgpu_plan(int64_t numbins, int64_t N, double dt, int zmax, int numharm, double sigma,
                   double flo, double fhi, int64_t lobin, accelgpu_setup *out)
 {
@@ -1533,7 +1555,7 @@ void accelgpu_destroy(accelgpu_ctx *ctx)
                    ctx->tw_fwd_full.tw2, ctx->tw_fwd_half.tw1, ctx->tw_fwd_half.tw2,
                    ctx->d_own[0], ctx->d_own[1], ctx->d_own[2], ctx->d_blk_lobin, ctx->d_blk_col, ctx->d_blk_numdata,
                    ctx->d_blk_ncols, ctx->d_blockfft, ctx->d_plane, ctx->d_hi, ctx->d_lo, ctx->d_flags, ctx->d_rowoff, ctx->d_rowchg, ctx->d_rowhalf, ctx->d_tmp, ctx->d_one_lobin, ctx->d_one_col,
-                   ctx->d_one_numdata, ctx->d_one_ncols, ctx->d_one_blockfft, ctx->d_mx, ctx->d_rowmx, ctx->d_work, ctx->d_ctl};
+                   ctx->d_one_numdata, ctx->d_one_ncols, ctx->d_one_blockfft, ctx->d_mx, ctx->d_rowmx, ctx->d_work, ctx->d_ctl, ctx->d_blk_zrange};
     for (void *p : dev)
         if (p) (void) hipFree(p);
     free_subbanks(ctx);
@@ -1636,7 +1658,7 @@ int accelgpu_get_tuning(accelgpu_ctx *ctx, const char *name, int *value)
         return ACCELGPU_OK;
     }
     if (!strcmp(name, "hs_prefilter_active")) { // read-only: does the coarse bound (group maxima) run in front of the sum?
-        *value = ctx->have_search && prefilter_wanted(ctx) && ctx->nblk_active == ctx->nblk ? 1 : 0;
+        *value = ctx->have_search && prefilter_wanted(ctx) ? 1 : 0;
         return ACCELGPU_OK;
     }
     if (!strcmp(name, "hs_bound_active")) { // read-only: is the plane kept as halves and summed over its bounds?
@@ -1932,29 +1954,12 @@ int set_search_impl(accelgpu_ctx *ctx, const accelgpu_setup *s, int norm_type, f
     ctx->nph = nph;
 
     // block grid (reference src/accelsearch.c:143-161 and 165-218)
-    std::vector<int64_t> lobin, col;
-    std::vector<int> numdata, ncols;
-    const double step = ACCELGPU_USELEN * 0.5;
-    const int64_t search_col0 = (int64_t) std::floor(accelhost::calc_required_r(1.0, s->rlo)) * 2;
-    int nprepop = 0, nsearch = 0;
-    for (double r = 8; r < s->rlo; r += step) {
-        const BlockDesc d = describe_block(r, ctx->halfwidth);
-        lobin.push_back(d.lobin);
-        numdata.push_back(d.numdata);
-        col.push_back((int64_t) d.rlo * 2);
-        // columns at or above the first search column belong to the search blocks
-        ncols.push_back((int) std::max<int64_t>(
-            0, std::min<int64_t>(ACCELGPU_USELEN, search_col0 - (int64_t) d.rlo * 2)));
-        nprepop++;
-    }
-    for (double r = s->rlo; r + step < (double) s->highestbin; r += step) {
-        const BlockDesc d = describe_block(r, ctx->halfwidth);
-        lobin.push_back(d.lobin);
-        numdata.push_back(d.numdata);
-        col.push_back((int64_t) d.rlo * 2);
-        ncols.push_back(ACCELGPU_USELEN);
-        nsearch++;
-    }
+    accelhost::BlockGrid bg;
+    accelhost::block_grid(s->rlo, s->highestbin, ctx->halfwidth, &bg);
+    const std::vector<int64_t> &lobin = bg.lobin, &col = bg.col;
+    const std::vector<int> &numdata = bg.numdata, &ncols = bg.ncols;
+    const int nprepop = bg.nprepop, nsearch = bg.nsearch;
+    const int64_t search_col0 = bg.search_col0;
     const int nblk = nprepop + nsearch;
     for (int i = 0; i < nblk; i++)
         if (numdata[i] > ctx->fftlen / 2) {
@@ -1963,12 +1968,14 @@ int set_search_impl(accelgpu_ctx *ctx, const accelgpu_setup *s, int norm_type, f
         }
     ctx->nblk = nblk;
     ctx->nblk_active = nblk;
+    ctx->partial_fill = false;
     ctx->range_first = 0;
     ctx->range_count = nsearch;
     ctx->h_blk_lobin = lobin;
     ctx->h_blk_col = col;
     ctx->h_blk_numdata = numdata;
     ctx->h_blk_ncols = ncols;
+    ctx->grid_host = bg;
     ctx->nprepop = nprepop;
     ctx->nsearch = nsearch;
     ctx->setup.num_prepop_blocks = nprepop;
@@ -1987,10 +1994,12 @@ int set_search_impl(accelgpu_ctx *ctx, const accelgpu_setup *s, int norm_type, f
         const size_t want = (size_t) nblk;
         if (ctx->blk_cap < want) {
             for (void *p : {(void *) ctx->d_blk_lobin, (void *) ctx->d_blk_col,
-                            (void *) ctx->d_blk_numdata, (void *) ctx->d_blk_ncols})
+                            (void *) ctx->d_blk_numdata, (void *) ctx->d_blk_ncols, (void *) ctx->d_blk_zrange})
                 if (p) HIPCHK(hipFree(p));
             ctx->d_blk_lobin = ctx->d_blk_col = nullptr;
             ctx->d_blk_numdata = ctx->d_blk_ncols = nullptr;
+            ctx->d_blk_zrange = nullptr;
+            HIPCHK(hipMalloc((void **) &ctx->d_blk_zrange, want * sizeof(int2)));
             HIPCHK(hipMalloc((void **) &ctx->d_blk_lobin, want * sizeof(int64_t)));
             HIPCHK(hipMalloc((void **) &ctx->d_blk_col, want * sizeof(int64_t)));
             HIPCHK(hipMalloc((void **) &ctx->d_blk_numdata, want * sizeof(int)));
@@ -2113,44 +2122,23 @@ int accelgpu_set_block_range(accelgpu_ctx *ctx, int32_t first_block, int32_t num
         return ACCELGPU_ERR_ARG;
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    std::vector<char> need((size_t) ctx->nblk, 0);
     drop_graphs(ctx);
-    const int64_t col0 = ctx->col0;
-    if (num_blocks > 0) {
-        for (int k = 0; k < num_blocks; k++)
-            need[(size_t) ctx->nprepop + first_block + k] = 1;
-        // columns the sub-harmonic look-ups of the searched columns fall in
-        const int64_t ca = col0 + (int64_t) first_block * ACCELGPU_USELEN;
-        const int64_t cb = ca + (int64_t) num_blocks * ACCELGPU_USELEN - 1;
-        for (int st = 1; st < ctx->setup.numharmstages; st++)
-            for (int h = 1; h < (1 << st); h += 2) {
-                const int64_t lo = (ca * h + (1 << (st - 1))) >> st;
-                const int64_t hi = (cb * h + (1 << (st - 1))) >> st;
-                for (int b = 0; b < ctx->nblk; b++) {
-                    const int64_t c0 = ctx->h_blk_col[b];
-                    const int64_t c1 = c0 + ctx->h_blk_ncols[b] - 1; // columns this block writes
-                    if (ctx->h_blk_ncols[b] > 0 && c0 <= hi && c1 >= lo)
-                        need[b] = 1;
-                }
-            }
+    std::vector<int> z0, z1;
+    accelhost::block_range_need(&ctx->setup, ctx->grid_host, first_block, num_blocks, &z0, &z1, nullptr);
+    const bool whole = first_block == 0 && num_blocks == ctx->nsearch; // every block, every row: no row ranges needed
+    // The block grid on the device stays whole (the plane of group maxima is indexed by a block's place in it);
+    // a fill takes the rows of each block from this table, and blocks with none cost it a workgroup that
+    // returns at once.
+    std::vector<int2> zr((size_t) ctx->nblk);
+    size_t n = 0;
+    for (int b = 0; b < ctx->nblk; b++) {
+        zr[b] = whole ? make_int2(0, ctx->numz) : make_int2(z0[b], z1[b]);
+        n += zr[b].y > zr[b].x;
     }
-    std::vector<int64_t> lobin, col;
-    std::vector<int> numdata, ncols;
-    for (int b = 0; b < ctx->nblk; b++)
-        if (need[b]) {
-            lobin.push_back(ctx->h_blk_lobin[b]);
-            col.push_back(ctx->h_blk_col[b]);
-            numdata.push_back(ctx->h_blk_numdata[b]);
-            ncols.push_back(ctx->h_blk_ncols[b]);
-        }
-    const size_t n = lobin.size();
-    if (n) {
-        HIPCHK(hipMemcpy(ctx->d_blk_lobin, lobin.data(), n * sizeof(int64_t), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(ctx->d_blk_col, col.data(), n * sizeof(int64_t), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(ctx->d_blk_numdata, numdata.data(), n * sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(ctx->d_blk_ncols, ncols.data(), n * sizeof(int), hipMemcpyHostToDevice));
-    }
+    if (ctx->nblk > 0)
+        HIPCHK(hipMemcpy(ctx->d_blk_zrange, zr.data(), zr.size() * sizeof(int2), hipMemcpyHostToDevice));
     ctx->nblk_active = (int) n;
+    ctx->partial_fill = !whole;
     ctx->range_first = first_block;
     ctx->range_count = num_blocks;
     if (blocks_generated)
@@ -2219,7 +2207,7 @@ int accelgpu_run_launch(accelgpu_ctx *ctx)
     decide_prefilter(ctx);
     if (ctx->range_count > 0) {
         if ((rc = spectrum_ready(ctx, ctx->stream))) return rc;
-        const bool whole_grid = ctx->nblk_active == ctx->nblk && ctx->range_first == 0 && ctx->range_count == ctx->nsearch;
+        const bool whole_grid = !ctx->partial_fill && ctx->range_first == 0 && ctx->range_count == ctx->nsearch;
         const bool small = ctx->setup.plane_bytes <= ((int64_t) 64 << 20);
         if (ctx->tune.use_graph && small && whole_grid && ctx->tune.hs_chunk_blocks == 0 && !ctx->profiling &&
             ctx->stream == ctx->own_stream) {

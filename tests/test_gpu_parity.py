@@ -300,27 +300,43 @@ def test_golden_fixture(gpu):
     assert np.abs(k[::16] - g["kernel_z10"]).max() <= 4e-6 * np.abs(g["kernel_z10"]).max()
 
 
+@pytest.mark.parametrize("hs_bound", [1, 4])
+@pytest.mark.parametrize("by_cost", [False, True])
 @pytest.mark.parametrize("world", [2, 3, 8])
-def test_block_range_split_equals_whole_search(gpu, world):
-    """One long series split into `world` block ranges (each regenerating the plane
-    blocks its look-ups need) gives, after merging, exactly the hits of one search."""
+def test_block_range_split_equals_whole_search(gpu, world, by_cost, hs_bound):
+    """One long series split into `world` block ranges -- of equal length, or of equal predicted work (uneven) --
+    each regenerating the plane rows its look-ups need and no others, gives, after merging, exactly the hits of
+    one search.  hs_bound = 4: with the coarse bound (group maxima written for the generated rows alone)."""
     import presto_amd as pa
     from presto_amd import batch
     numbins = 1 << 18
     fft = synth.noise_fft(numbins, 31, lines=[(20000.5, 12.0, 11.0), (150001.0, -40.0, 12.0), (4000.0, 0.0, 9.0)])
     setup = gpu.configure(numbins, 2 * numbins, 1e-3, 60, 16, flo=0.3, fhi=1e9)
     gpu.load_fft(fft)
+    gpu.set_tuning("hs_bound", hs_bound)
+    try:
+        _block_range_split(gpu, setup, world, by_cost, batch)
+    finally:
+        gpu.set_tuning("hs_bound", 1)
+
+
+def _block_range_split(gpu, setup, world, by_cost, batch):
+    from presto_amd.api import block_range_need
     whole = gpu.run()
     total_blocks = setup.num_search_blocks + setup.num_prepop_blocks
     parts, generated = [], []
+    ranges = batch.split_blocks_by_cost(setup, world) if by_cost else batch.split_blocks(setup.num_search_blocks, world)
+    assert ranges[0][0] == 0 and ranges[-1][1] == setup.num_search_blocks
+    assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
     for rank in range(world):
-        first, last = batch.split_blocks(setup.num_search_blocks, world)[rank]
+        first, last = ranges[rank]
+        assert block_range_need(setup, first, last - first)[0] <= total_blocks
         # scribble over the plane so that nothing survives from the previous range
         for z in (0, setup.numz // 2, setup.numz - 1):
             gpu.put_plane(z, 0, np.full(setup.rlen, 1e9, dtype=np.float32))
         generated.append(gpu.set_block_range(first, last - first))
         parts.append(gpu.run())
-        if last > first:
+        if len(parts[-1]):
             assert parts[-1]["block"].min() >= first and parts[-1]["block"].max() < last
     merged = batch.reference_order(np.concatenate(parts))
     assert np.array_equal(merged, whole)

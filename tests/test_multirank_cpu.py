@@ -46,6 +46,32 @@ def test_shard_and_split():
     assert batch.split_blocks(3, 8)[3:] == [(3, 3)] * 5
 
 
+def test_split_by_cost_balances_the_ranks():
+    """One long series (2^27 points, zmax 300, 16 harmonics) over 2, 4 and 8 ranks: ranges cut for equal predicted
+    work are contiguous, cover every search block, and leave the slowest rank within 15 % of the mean; equal
+    searched ranges do not (the top rank regenerates half the plane, the bottom one an eighth)."""
+    from presto_amd.api import plan, block_range_need
+    N = 1 << 27
+    s = plan(N // 2, N, 64e-6, 300, 16, fhi=1e9)
+    nb = s.num_search_blocks
+    blocks, rows = block_range_need(s, 0, nb)
+    # the whole range: every block; the blocks below the search region only serve as sources, and no harmonic reaches
+    # their outermost rows
+    assert blocks == nb + s.num_prepop_blocks and nb * s.numz < rows <= blocks * s.numz
+    assert block_range_need(s, 0, 0) == (0, 0)
+    for world in (2, 4, 8):
+        r = batch.split_blocks_by_cost(s, world)
+        assert r[0][0] == 0 and r[-1][1] == nb and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+        cost = [batch.range_cost(s, a, b - a) for a, b in r]
+        assert max(cost) <= 1.15 * sum(cost) / world
+        assert max(cost) < batch.range_cost(s, 0, nb) / (1.0 + 0.3 * np.log2(world))   # and it is worth splitting
+    even = [batch.range_cost(s, a, b - a) for a, b in batch.split_blocks(nb, 8)]
+    assert max(even) > 1.3 * sum(even) / 8
+    # a source-only block is generated for the rows its harmonics reach, not whole: the top eighth's need
+    blocks, rows = block_range_need(s, nb - nb // 8, nb // 8)
+    assert rows < 0.7 * blocks * s.numz
+
+
 @pytest.mark.timeout(120)
 def test_allgather_merge_world2():
     world, ntrials = 2, 7
@@ -90,12 +116,14 @@ def _range_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     allhits = _fake_hits(37, 5)
-    first, last = batch.split_blocks(37, world)[rank]
+    from presto_amd.api import plan
+    real = plan(37 * 3735 + 3000, 2 * (37 * 3735 + 3000), 1e-3, 20, 8, flo=0.2, fhi=1e9)   # host arithmetic only
+    assert real.num_search_blocks == 37
+    first, last = batch.split_blocks_by_cost(real, world)[rank]
     mine = allhits[(allhits["block"] >= first) & (allhits["block"] < last)]
 
     class FakeGPU:                      # stands in for AccelSearchGPU on a CPU-only box
-        class setup:
-            num_search_blocks = 37
+        setup = real
 
         def set_block_range(self, a, n):
             assert (a, n) == (first, last - first)
