@@ -82,6 +82,10 @@ int accelgpu_create(accelgpu_ctx **ctx, int device);
 void accelgpu_destroy(accelgpu_ctx *ctx);
 /* Use the caller's hipStream_t instead of the context's own (NULL restores it). */
 int accelgpu_set_stream(accelgpu_ctx *ctx, void *hip_stream);
+/* Makes the context's GPU the current device of the calling thread: for a helper thread (a file
+ * reader) that calls accelgpu_host_alloc() for the context's uploads.  Every entry point that
+ * takes a context does the same for its own thread. */
+int accelgpu_bind_thread(accelgpu_ctx *ctx);
 /* Waits for everything the context has queued, uploads included. */
 int accelgpu_synchronize(accelgpu_ctx *ctx);
 
@@ -389,6 +393,12 @@ int accelgpu_nice_output(int error_digits, double val, double err, char *out, in
 int accelgpu_write_accel_files(const accelgpu_setup *setup, const accelgpu_optcand *cands,
                                int64_t n, float nph, const char *accel_path,
                                const char *cand_path, const char *inf_text);
+
+/* The work file of a search (<root>_ACCEL_<zmax>.txtcand): one line per hit that the candidate list took,
+ * in the order it took them -- hits, sigma and added as accelgpu_replay_candidates() returned them.  Host only.
+ * ref: the fprintf in search_ffdotpows(), src/accel_utils.c:1290-1294. */
+int accelgpu_write_txtcand(const accelgpu_setup *setup, const accelgpu_hit *hits, const float *sigma,
+                           const int32_t *added, int64_t n, const char *path);
 
 /* What the sifting step reads back from an ACCEL file for one fundamental, taken from
  * the optimised candidate at the precision the file prints it with (so that a list

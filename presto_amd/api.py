@@ -68,6 +68,7 @@ def load_library():
     L.accelgpu_destroy.argtypes = [vp]; L.accelgpu_destroy.restype = None
     L.accelgpu_set_stream.argtypes = [vp, vp]
     L.accelgpu_synchronize.argtypes = [vp]
+    L.accelgpu_bind_thread.argtypes = [vp]
     L.accelgpu_z_resp_halfwidth.argtypes = [d]
     L.accelgpu_calc_fftlen.argtypes = [i, i, i]
     L.accelgpu_coarse_bound_applies.argtypes = [i, i64, i64, i, i]
@@ -95,6 +96,7 @@ def load_library():
     L.accelgpu_calc_props.argtypes = [vp, d, d, d, vp]
     L.accelgpu_nice_output.argtypes = [i, d, d, C.c_char_p, i]
     L.accelgpu_write_accel_files.argtypes = [pS, vp, i64, f, C.c_char_p, C.c_char_p, C.c_char_p]
+    L.accelgpu_write_txtcand.argtypes = [pS, vp, vp, vp, i64, C.c_char_p]
     L.accelgpu_sort_and_eliminate.argtypes = [vp, i64, i, C.POINTER(i64)]
     L.accelgpu_optimize_cands.argtypes = [vp, vp, i64, i, vp]
     L.accelgpu_sift_records.argtypes = [vp, i64, f, vp]
@@ -233,6 +235,15 @@ def block_range_need(setup, first_block, num_blocks):
     return nb.value, rows.value
 
 
+def write_txtcand(setup, hits, sigma, added, path):
+    """The search's work file from what replay_candidates() returned (one C call; it releases the interpreter lock)."""
+    hits = np.ascontiguousarray(hits)
+    sigma = np.ascontiguousarray(sigma, dtype=np.float32)
+    added = np.ascontiguousarray(added, dtype=np.int32)
+    _check(load_library().accelgpu_write_txtcand(C.byref(setup), hits.ctypes.data, sigma.ctypes.data, added.ctypes.data,
+                                                 len(hits), path.encode()))
+
+
 def replay_candidates(setup, hits):
     """Host replay: returns (cands, sigma per hit, added flag per hit)."""
     L = load_library()
@@ -353,6 +364,11 @@ class AccelSearchGPU:
         """Upload from a PinnedSpectrum without waiting; the launch waits on the device."""
         _check(self.L.accelgpu_load_fft_async(self._h, C.c_void_p(pinned._p.value), pinned.array.size))
         self._keep_next = pinned
+
+    def bind_thread(self):
+        """Makes the context's GPU the current device of the calling thread (for a helper thread that
+        allocates page-locked memory)."""
+        _check(self.L.accelgpu_bind_thread(self._h))
 
     def set_tuning(self, name, value):
         _check(self.L.accelgpu_set_tuning(self._h, name.encode(), int(value)))

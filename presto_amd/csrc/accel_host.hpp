@@ -61,6 +61,8 @@ std::string nice_output_1(double val, double err);
 std::string nice_output_2(double val, double err, bool *ok);
 int calc_props(const accelgpu_rderivs &d, double r, double z, double w, accelgpu_fourierprops *out);
 int sift_records(const accelgpu_optcand *cands, int64_t n, float nph, accelgpu_siftrec *out);
+int write_txtcand(const accelgpu_setup *su, const accelgpu_hit *hits, const float *sigma, const int32_t *added, int64_t n,
+                  const char *path);
 int write_accel_files(const accelgpu_setup *su, const accelgpu_optcand *cands, int64_t n, float nph,
                       const char *accel_path, const char *cand_path, const char *inf_text);
 

@@ -282,6 +282,32 @@ void put_text(FILE *f, const std::string &s, int width) { fprintf(f, "%s  ", cen
 
 } // namespace
 
+int write_txtcand(const accelgpu_setup *su, const accelgpu_hit *hits, const float *sigma, const int32_t *added, int64_t n,
+                  const char *path)
+{
+    if (!su || !path || (n > 0 && (!hits || !sigma || !added)) || !(su->T > 0.0)) {
+        set_error("write_txtcand: bad arguments");
+        return ACCELGPU_ERR_ARG;
+    }
+    FILE *w = fopen(path, "w");
+    if (!w) {
+        set_error("cannot open '%s' for writing", path);
+        return ACCELGPU_ERR_ARG;
+    }
+    // one line per hit the list took, in the order it took them (src/accel_utils.c:1290-1294)
+    for (int64_t i = 0; i < n; i++)
+        if (added[i]) {
+            const int nh = 1 << hits[i].stage;
+            const double rr = hits[i].rind * 0.5 / nh, zz = (su->zlo + hits[i].zind * 2.0) / nh;
+            fprintf(w, "%-7.2f  %-7.4f  %-2d  %-14.4f  %-14.9f  %-10.4f\n", hits[i].power, sigma[i], nh, rr, rr / su->T, zz);
+        }
+    if (fclose(w) != 0) {
+        set_error("error writing '%s'", path);
+        return ACCELGPU_ERR_ARG;
+    }
+    return ACCELGPU_OK;
+}
+
 int write_accel_files(const accelgpu_setup *su, const accelgpu_optcand *cands, int64_t n, float nph,
                       const char *accel_path, const char *cand_path, const char *inf_text)
 {

@@ -1684,6 +1684,11 @@ int accelgpu_set_stream(accelgpu_ctx *ctx, void *hip_stream)
     return ACCELGPU_OK;
 }
 
+int accelgpu_bind_thread(accelgpu_ctx *ctx)
+{
+    return use(ctx);
+}
+
 int accelgpu_synchronize(accelgpu_ctx *ctx)
 {
     int rc = use(ctx);

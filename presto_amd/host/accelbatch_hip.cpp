@@ -9,8 +9,10 @@
 // candidate trimming, optimisation, <root>_ACCEL_<zmax> and .cand.  Here the files move
 // through three stages at once: a reader thread has the next file in memory, the GPU
 // searches the current one (its upload and preparation ran beside the previous search),
-// and the host finishes the previous one -- list replay, work file, trimming, and the
-// optimisation of its candidates on the device beside the running search.  The zapping
+// and the host finishes the previous one -- list replay, trimming, and the optimisation of
+// its candidates on the device beside the running search; a writer thread writes the work
+// file and the result files.  Spectra are read straight into page-locked buffers and
+// uploaded from there without the host waiting.  The zapping
 // and red-noise steps of the survey scripts (zapbirds -zap, rednoise, :367-377) run on
 // the spectrum in device memory instead of as file-to-file passes: -zaplist applies to
 // every input here (accelsearch itself zaps only a time series), -rednoise to .fft input
@@ -22,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -63,7 +66,8 @@ struct Trial {
     bool dat_input = false;
     double N = 0, dt = 0;
     int64_t numbins = 0;
-    std::vector<float> data;     // packed spectrum (2*numbins floats) or the time series
+    std::vector<float> data;     // the time series (.dat / .sdat input)
+    float *pinned = nullptr;     // packed spectrum (2*numbins floats) in a page-locked buffer of the pool (.fft input)
     accelgpu_setup setup{};
     int name_zmax = 0;           // -zmax as given: the reference names its files before it rounds zmax up
                                  // to an even number (src/accel_utils.c:1492-1494, then :1526)
@@ -71,8 +75,51 @@ struct Trial {
     std::vector<accelgpu_cand> kept;
 };
 
+// Page-locked host buffers for spectra on their way to the GPU, all of one size (a batch's files are
+// alike; a file of another size is read into ordinary memory and uploaded the blocking way).
+class PinnedPool {
+  public:
+    float *get(size_t floats) // nullptr: not a size this pool serves
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        if (floats_ == 0) {
+            floats_ = floats;
+            for (int i = 0; i < 6; i++) {
+                void *p = nullptr;
+                if (accelgpu_host_alloc(&p, floats * sizeof(float)))
+                    break;
+                all_.push_back((float *) p);
+                free_.push_back((float *) p);
+            }
+        }
+        if (floats != floats_ || all_.empty())
+            return nullptr;
+        some_.wait(lk, [&] { return !free_.empty(); });
+        float *p = free_.back();
+        free_.pop_back();
+        return p;
+    }
+    void put(float *p)
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        free_.push_back(p);
+        some_.notify_one();
+    }
+    ~PinnedPool()
+    {
+        for (float *p : all_)
+            (void) accelgpu_host_free(p);
+    }
+
+  private:
+    std::mutex m_;
+    std::condition_variable some_;
+    size_t floats_ = 0;
+    std::vector<float *> all_, free_;
+};
+
 // Host side of the input; no GPU call, runs on the reader thread.
-std::unique_ptr<Trial> read_trial(const std::string &path)
+std::unique_ptr<Trial> read_trial(const std::string &path, PinnedPool &pool)
 {
     std::unique_ptr<Trial> t(new Trial);
     t->path = path;
@@ -118,8 +165,13 @@ std::unique_ptr<Trial> read_trial(const std::string &path)
         t->numbins = (int64_t) (n / 2);
     } else {
         const size_t n = (size_t) (bytes / 4);
-        t->data.resize(n);
-        ok = fread(t->data.data(), 4, n, f) == n;
+        float *dst = t->dat_input ? nullptr : pool.get(n);
+        t->pinned = dst;
+        if (!dst) {
+            t->data.resize(n);
+            dst = t->data.data();
+        }
+        ok = fread(dst, 4, n, f) == n;
         t->numbins = (int64_t) (n / 2);
     }
     fclose(f);
@@ -186,6 +238,8 @@ void stage_trial(accelgpu_ctx *gpu, Trial &t, const Options &o, Geometry &geo, a
         if (accelgpu_load_dat(gpu, t.data.data(), (int64_t) t.data.size(), 1)) die("accelgpu_load_dat");
         // no -photon here: bin 0 becomes (1, 1) as in src/accel_utils.c:1553-1556
         if (accelgpu_set_bin0(gpu, 1.0f, 1.0f)) die("accelgpu_set_bin0");
+    } else if (t.pinned) { // no host wait: the launch waits for the copy on the device
+        if (accelgpu_load_fft_async(gpu, t.pinned, t.numbins)) die("accelgpu_load_fft_async");
     } else if (accelgpu_load_fft(gpu, t.data.data(), t.numbins)) {
         die("accelgpu_load_fft");
     }
@@ -216,38 +270,79 @@ void stage_trial(accelgpu_ctx *gpu, Trial &t, const Options &o, Geometry &geo, a
     if (accelgpu_run_launch(gpu)) die("accelgpu_run_launch");
 }
 
-// Collect a launched trial: list replay, work file, trimming, optimisation queued.
-void collect_trial(accelgpu_ctx *gpu, Trial &t, const Options &o, std::vector<accelgpu_hit> &hits)
+// File writing off the launch path: jobs run in the order they were handed over.
+class Writer {
+  public:
+    Writer() : th_([this] { run(); }) {}
+    ~Writer() { finish(); }
+    void submit(std::function<void()> job)
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        q_.push_back(std::move(job));
+        some_.notify_one();
+    }
+    void finish()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            if (done_) return;
+            done_ = true;
+            some_.notify_one();
+        }
+        th_.join();
+    }
+
+  private:
+    void run()
+    {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                some_.wait(lk, [&] { return done_ || !q_.empty(); });
+                if (q_.empty())
+                    return;
+                job = std::move(q_.front());
+                q_.pop_front();
+            }
+            job();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable some_;
+    std::deque<std::function<void()>> q_;
+    bool done_ = false;
+    std::thread th_;
+};
+
+// Collect a launched trial: list replay, work file (to the writer), trimming, optimisation queued.
+void collect_trial(accelgpu_ctx *gpu, Trial &t, const Options &o, PinnedPool &pool, Writer &writer)
 {
     const accelgpu_setup &su = t.setup;
     int64_t nhits = 0;
     int rc;
-    while ((rc = accelgpu_run_collect(gpu, hits.data(), (int64_t) hits.size(), &nhits)) == ACCELGPU_ERR_OVERFLOW &&
-           nhits > (int64_t) hits.size())
-        hits.resize((size_t) nhits + 1024);
+    auto hits = std::make_shared<std::vector<accelgpu_hit>>((size_t) 1 << 18);
+    while ((rc = accelgpu_run_collect(gpu, hits->data(), (int64_t) hits->size(), &nhits)) == ACCELGPU_ERR_OVERFLOW &&
+           nhits > (int64_t) hits->size())
+        hits->resize((size_t) nhits + 1024);
     if (rc) die("accelgpu_run_collect");
+    if (t.pinned) { // the search has read its spectrum on the device: the host buffer is free
+        pool.put(t.pinned);
+        t.pinned = nullptr;
+    }
     std::vector<accelgpu_cand> cands((size_t) nhits + 1);
-    std::vector<float> sig((size_t) nhits + 1);
-    std::vector<int32_t> added((size_t) nhits + 1);
+    auto sig = std::make_shared<std::vector<float>>((size_t) nhits + 1);
+    auto added = std::make_shared<std::vector<int32_t>>((size_t) nhits + 1);
     int64_t ncands = 0;
-    if (accelgpu_replay_candidates(&su, hits.data(), nhits, cands.data(), (int64_t) cands.size(), &ncands, sig.data(),
-                                   added.data()))
+    if (accelgpu_replay_candidates(&su, hits->data(), nhits, cands.data(), (int64_t) cands.size(), &ncands, sig->data(),
+                                   added->data()))
         die("accelgpu_replay_candidates");
     if (!t.dat_input) { // the work file of the search (src/accel_utils.c:1290-1294)
         const std::string work = t.root + "_ACCEL_" + std::to_string(t.name_zmax) + ".txtcand";
-        FILE *w = fopen(work.c_str(), "w");
-        if (!w) {
-            perror(work.c_str());
-            exit(1);
-        }
-        for (int64_t i = 0; i < nhits; i++)
-            if (added[(size_t) i]) {
-                const int nh = 1 << hits[(size_t) i].stage;
-                const double rr = hits[(size_t) i].rind * 0.5 / nh, zz = (su.zlo + hits[(size_t) i].zind * 2.0) / nh;
-                fprintf(w, "%-7.2f  %-7.4f  %-2d  %-14.4f  %-14.9f  %-10.4f\n", hits[(size_t) i].power,
-                        sig[(size_t) i], nh, rr, rr / su.T, zz);
-            }
-        fclose(w);
+        writer.submit([su, hits, sig, added, nhits, work] {
+            if (accelgpu_write_txtcand(&su, hits->data(), sig->data(), added->data(), nhits, work.c_str()))
+                die("accelgpu_write_txtcand");
+        });
     }
     t.nopt = 0;
     if (ncands > 0) {
@@ -263,17 +358,21 @@ void collect_trial(accelgpu_ctx *gpu, Trial &t, const Options &o, std::vector<ac
                (long long) ncands, (long long) t.nopt);
 }
 
-// Wait for the optimisation and write the result files.
-void write_trial(accelgpu_ctx *gpu, Trial &t)
+// Wait for the optimisation and hand the result files to the writer.
+void write_trial(accelgpu_ctx *gpu, Trial &t, Writer &writer)
 {
     if (t.nopt == 0)
         return;
-    std::vector<accelgpu_optcand> opt((size_t) t.nopt);
-    if (accelgpu_optimize_collect(gpu, opt.data(), t.nopt)) die("accelgpu_optimize_collect");
+    auto opt = std::make_shared<std::vector<accelgpu_optcand>>((size_t) t.nopt);
+    if (accelgpu_optimize_collect(gpu, opt->data(), t.nopt)) die("accelgpu_optimize_collect");
     const std::string accelnm = t.root + "_ACCEL_" + std::to_string(t.name_zmax);
-    if (accelgpu_write_accel_files(&t.setup, opt.data(), t.nopt, 0.f, accelnm.c_str(), (accelnm + ".cand").c_str(),
-                                   t.inftext.c_str()))
-        die("accelgpu_write_accel_files");
+    const accelgpu_setup su = t.setup;
+    const std::string inftext = t.inftext;
+    writer.submit([su, opt, accelnm, inftext] {
+        if (accelgpu_write_accel_files(&su, opt->data(), (int64_t) opt->size(), 0.f, accelnm.c_str(), (accelnm + ".cand").c_str(),
+                                       inftext.c_str()))
+            die("accelgpu_write_accel_files");
+    });
 }
 
 } // namespace
@@ -325,30 +424,33 @@ int main(int argc, char **argv)
     if (accelgpu_create(&gpu, o.device)) die("accelgpu_create");
 
     Mailbox box;
+    PinnedPool pool;
+    Writer writer;
     std::thread reader([&] {
+        (void) accelgpu_bind_thread(gpu); // page-locked memory is asked of the context's device
         for (const std::string &f : files)
-            box.put(read_trial(f));
+            box.put(read_trial(f, pool));
         box.put(nullptr);
     });
 
     Geometry geo;
     accelgpu_setup su{};
     Birds birds;
-    std::vector<accelgpu_hit> hits((size_t) 1 << 18);
     std::unique_ptr<Trial> launched, optimising;
     // One step for the trials behind the newest launch: the older optimisation's results
     // out to the files, the collected search's candidates to the device.
     auto advance = [&] {
         if (optimising) {
-            write_trial(gpu, *optimising);
+            write_trial(gpu, *optimising, writer);
             optimising.reset();
         }
         if (launched) {
-            collect_trial(gpu, *launched, o, hits);
+            collect_trial(gpu, *launched, o, pool, writer);
             optimising = std::move(launched);
         }
     };
     size_t done = 0;
+    std::chrono::steady_clock::time_point t_first; // when the first file's search was launched: set-up ends here
     for (;;) {
         std::unique_ptr<Trial> t = box.get();
         if (!t)
@@ -365,13 +467,20 @@ int main(int argc, char **argv)
         launched = std::move(prev);
         advance();                               // host work and optimisation overlap t's search
         launched = std::move(t);
-        done++;
+        if (done++ == 0)
+            t_first = std::chrono::steady_clock::now();
     }
     advance();
     advance();
     reader.join();
-    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    printf("\n%zu files in %.3f sec (%.1f files/s)\n\n", done, secs, done / secs);
+    writer.finish();
+    const auto t1 = std::chrono::steady_clock::now();
+    const double secs = std::chrono::duration<double>(t1 - t0).count();
+    const double steady = std::chrono::duration<double>(t1 - t_first).count();
+    // the second figure leaves out what happens once per process (device and context start-up, template bank,
+    // allocating and clearing the plane) and the first file's read
+    printf("\n%zu files in %.3f sec (%.1f files/s; %.1f files/s from the first launch on)\n\n", done, secs, done / secs,
+           done > 1 ? (done - 1) / steady : 0.0);
     accelgpu_destroy(gpu);
     return 0;
 }

@@ -62,17 +62,58 @@ def read_inf(root):
 
 class _Trial:
     """One input file on its way through the GPU."""
-    __slots__ = ("index", "path", "root", "ext", "N", "dt", "data", "numbins", "setup", "t0", "nopt")
+    __slots__ = ("index", "path", "root", "ext", "N", "dt", "data", "numbins", "setup", "t0", "nopt", "pinned", "work_file")
 
 
-def read_trial(index, path):
+class PinnedPool:
+    """Page-locked host buffers for the spectra on their way to the GPU: the reader thread reads a file
+    straight into one, the upload from it is asynchronous (the copy engine works beside the running
+    searches and the host does not wait), and the buffer comes back when its trial has been collected.
+    One set of `count` buffers per spectrum length, made when the first file of that length turns up."""
+
+    def __init__(self, count=6):
+        import queue
+        self._queue = queue
+        self.count = count
+        self.free = {}
+
+    def get(self, numbins):
+        from . import api
+        if numbins not in self.free:
+            q = self._queue.Queue()
+            for _ in range(self.count):
+                q.put(api.PinnedSpectrum(numbins))
+            self.free[numbins] = q
+        return self.free[numbins].get()
+
+    def put(self, ps):
+        self.free[ps.array.size].put(ps)
+
+    def close(self):
+        for q in self.free.values():
+            while not q.empty():
+                q.get().free()
+        self.free = {}
+
+
+def read_trial(index, path, pool=None):
     """Host side of the input: the .inf numbers and the samples (no GPU call; runs on the
-    reader thread, numpy releases the interpreter lock while it reads)."""
+    reader thread, the read releases the interpreter lock).  With a `pool`, a spectrum is read
+    into page-locked memory."""
     t = _Trial()
     t.index, t.path, t.t0 = index, path, time.perf_counter()
     t.root, t.ext = os.path.splitext(path)
     t.N, t.dt = read_inf(t.root)
-    if t.ext == ".fft":
+    t.pinned = t.work_file = None
+    if t.ext == ".fft" and pool is not None:
+        t.numbins = os.path.getsize(path) // 8
+        t.pinned = pool.get(t.numbins)
+        t.data = t.pinned.array
+        with open(path, "rb", buffering=0) as f:
+            got = f.readinto(memoryview(t.data).cast("B"))
+        if got != 8 * t.numbins:
+            raise ValueError("short read on %s" % path)
+    elif t.ext == ".fft":
         t.data = np.fromfile(path, dtype=np.complex64)
         t.numbins = t.data.size
     elif t.ext in (".dat", ".sdat"):
@@ -103,6 +144,8 @@ def stage_trial(gpu, t, opts, state):
         if dat_input:
             gpu.load_dat(t.data, deredden=True)
             gpu.set_bin0(1.0, 1.0)          # no -photon here (src/accel_utils.c:1553-1556)
+        elif t.pinned is not None:
+            gpu.load_fft_async(t.pinned)    # no host wait: the launch waits for the copy on the device
         else:
             gpu.load_fft(t.data)
         t.data = None
@@ -114,29 +157,26 @@ def stage_trial(gpu, t, opts, state):
         gpu.run_launch()
 
 
-def collect_trial(gpu, t, opts):
+def collect_trial(gpu, t, opts, writer=None, pool=None):
     """First part of what follows a launch: collect the hits, replay the candidate list,
-    write the work file, trim the list and queue its optimisation on the device (against
-    this trial's spectrum, beside the next trial's search)."""
+    write the work file (on the `writer` executor if there is one), trim the list and queue its
+    optimisation on the device (against this trial's spectrum, beside the next trial's search)."""
     from . import api
     setup = t.setup
-    T = t.N * t.dt
     with _timed("collect"):
         hits = gpu.run_collect(max_hits=1 << 18)
+    if t.pinned is not None and pool is not None:
+        pool.put(t.pinned)                  # the search has read its spectrum on the device: the host buffer is free
+        t.pinned = None
     with _timed("replay"):
         cands, sig, added = api.replay_candidates(setup, hits)
     accelnm = "%s_ACCEL_%d" % (t.root, opts.zmax)    # as given: named before zmax is rounded up (src/accel_utils.c:1492-1494, 1526)
     if t.ext == ".fft":                     # the work file of the search (src/accel_utils.c:1291-1294)
         with _timed("txtcand"):
-            sel = added != 0
-            h, s = hits[sel], sig[sel]
-            nh = 1 << h["stage"].astype(np.int64)
-            rr = h["rind"] * 0.5 / nh
-            zz = (setup.zlo + h["zind"] * 2.0) / nh
-            with open(accelnm + ".txtcand", "w") as f:
-                f.write("".join("%-7.2f  %-7.4f  %-2d  %-14.4f  %-14.9f  %-10.4f\n" % row
-                                for row in zip(h["power"].tolist(), s.tolist(), nh.tolist(), rr.tolist(),
-                                               (rr / T).tolist(), zz.tolist())))
+            if writer is None:
+                api.write_txtcand(setup, hits, sig, added, accelnm + ".txtcand")
+            else:
+                t.work_file = writer.submit(api.write_txtcand, setup, hits, sig, added, accelnm + ".txtcand")
     t.nopt = 0
     if len(cands):
         with _timed("optimize launch"):
@@ -157,6 +197,8 @@ def write_trial(gpu, t, opts, writer=None):
             opt = gpu.optimize_collect(t.nopt)
 
     def write_results():
+        if t.work_file is not None:
+            t.work_file.result()            # (queued before this on the same worker: done; a failure surfaces here)
         if opt is None:
             return sifting.Candlist([])
         with _timed("result files"):
@@ -186,11 +228,13 @@ def search_files(gpu, files, indices, opts, depth=2):
     import threading
     from concurrent.futures import ThreadPoolExecutor
     q = queue.Queue(maxsize=depth)
+    pool = PinnedPool(depth + 4)            # queued + being read + two in flight + one spare
 
     def reader():
         try:
+            gpu.bind_thread()               # page-locked memory is asked of the context's device
             for i in indices:
-                q.put(read_trial(i, files[i]))
+                q.put(read_trial(i, files[i], pool))
             q.put(None)
         except BaseException as e:          # hand the failure to the consumer
             q.put(e)
@@ -221,7 +265,7 @@ def search_files(gpu, files, indices, opts, depth=2):
             written.append((optimising.index, write_trial(gpu, optimising, opts, writer)))
             optimising = None
         if launched is not None:
-            collect_trial(gpu, launched, opts)
+            collect_trial(gpu, launched, opts, writer, pool)
             optimising, launched = launched, None
 
     try:
@@ -246,6 +290,8 @@ def search_files(gpu, files, indices, opts, depth=2):
     finally:
         writer.shutdown(wait=True)
     th.join()
+    gpu.synchronize()
+    pool.close()
 
 
 def candlist_to_records(cl, file_index):

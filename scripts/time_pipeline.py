@@ -15,12 +15,15 @@ ndistinct = min(nfiles, 8)
 cfg = dict(synth.CONFIGS["cfg2"])
 tmp = tempfile.mkdtemp(prefix="pipe_", dir="/tmp")
 files = []
+roots = []
 for k in range(nfiles):
     root = os.path.join(tmp, "beam_DM%.2f" % (10.0 + k))
     if k < ndistinct:
-        spec = synth.make_fft(cfg["N"], cfg["dt"], cfg["pulsars"], seed=1000 + k)
-        specs = specs + [spec] if k else [spec]
-    synth.write_fft(root, specs[k % ndistinct], cfg["N"], cfg["dt"])
+        synth.write_fft(root, synth.make_fft(cfg["N"], cfg["dt"], cfg["pulsars"], seed=1000 + k), cfg["N"], cfg["dt"])
+    else:                                    # further trials: other names for the same bytes (results go by the name)
+        os.symlink(roots[k % ndistinct] + ".fft", root + ".fft")
+        os.symlink(roots[k % ndistinct] + ".inf", root + ".inf")
+    roots.append(root)
     files.append(root + ".fft")
 opts = pipeline.parse_args(["-zmax", "200", "-numharm", "16", "-fhi", "1e9", "-verbosity", "0",
                             "-o", os.path.join(tmp, "beam")] + files)
@@ -28,8 +31,9 @@ for rep in range(2):
     t0 = time.perf_counter()
     cl, secs = pipeline.run(sorted(files), opts)
     dt = time.perf_counter() - t0
-    print("pass %d: %d files in %.3f s = %.1f files/s; per file %s ms; %d sifted candidates" % (
-        rep, nfiles, dt, nfiles / dt, " ".join("%.1f" % (1e3 * s) for s in secs), len(cl)))
+    print("pass %d: %d files in %.3f s = %.1f files/s (%.1f files/s after the first file: context, template bank and "
+          "plane are set up once per process); %d sifted candidates" % (
+              rep, nfiles, dt, nfiles / dt, (nfiles - 1) / max(sum(secs[1:]), 1e-9), len(cl)))
     print("    ms per file: " + "  ".join("%s %.2f" % (k, 1e3 * v / nfiles) for k, v in pipeline.TIMES.items()))
     pipeline.TIMES.clear()
 
