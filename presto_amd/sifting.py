@@ -3,8 +3,14 @@
 Host-side consumer of the per-trial result files (or of the candidate records
 gathered over RCCL by presto_amd.batch): preliminary rejections, duplicate
 removal across DM trials, harmonic removal, DM-consistency checks and the
-candidate list report.  Same names, arguments, thresholds and results as the
-reference's module (lib/python/sifting.py); plotting is not part of it.
+candidate list report.  Names, arguments, thresholds, notes and file formats are
+those of the reference's module (lib/python/sifting.py), so that scripts written
+against it keep working; the cross-DM steps and the ACCEL-file parser are written
+afresh on columns and index sets (one stable sort by r with bisected windows for the
+duplicates, one broadcast comparison per fundamental for the harmonics, a verdict
+function for the DM tests, block-wise reading of the harmonics table).  Plotting is
+not part of it.  The reference module cannot run here (Python 2 + a compiled
+extension): tests are known answers plus outputs frozen from this module itself.
 
 Module-level thresholds can be overwritten by the importing script, as there
 (lib/python/sifting.py:13-38).
@@ -222,122 +228,158 @@ class Candlist(object):
         self.reject_harmpowcutoff()
         self.reject_rogueharmpow()
 
-    # -- across DM trials (:732-967) -----------------------------------------------
+    # -- across DM trials (rules of the reference's :732-967) ------------------------------
+    # The three steps below work on columns (r, f, sigma, power as arrays) and index sets rather than by
+    # popping list elements one at a time; what they keep, drop and note is what the reference's rules say.
+    def _columns(self):
+        c = self.cands
+        return (np.array([x.r for x in c], dtype=np.float64), np.array([x.f for x in c], dtype=np.float64),
+                np.array([x.sigma for x in c], dtype=np.float64), np.array([x.ipow_det for x in c], dtype=np.float64))
+
     def remove_duplicate_candidates(self, verbosity=1):
-        """Keep the most significant of the candidates within r_err bins of each other
-        and give it the others' hits."""
+        """Candidates within r_err bins of each other are one signal seen in several trials: the most
+        significant stays and collects the others' hits.  A run is measured from its first member in
+        frequency order; when a stronger member takes over, the run is measured again from that one, so a
+        chain can grow past r_err from where it began."""
+        n = len(self.cands)
         if verbosity >= 1:
-            print("  Sorting the %d candidates by frequency..." % self.get_numcands())
-        self.cands.sort(key=lambda c: c.r)
+            print("  Sorting the %d candidates by frequency..." % n)
+        r, _, sig, ipw = self._columns()
+        order = np.argsort(r, kind="stable")          # equal r: in the order given
+        rs = r[order]
         if verbosity >= 1:
             print("  Searching for dupes...")
-        ii = 0
-        while ii < len(self.cands):
-            jj = ii + 1
-            if jj < len(self.cands) and np.fabs(self.cands[ii].r - self.cands[jj].r) < r_err:
-                jj += 1
-                while jj < len(self.cands) and np.fabs(self.cands[ii].r - self.cands[jj].r) < r_err:
-                    jj += 1
-                best = sorted(self.cands[ii:jj], key=_by_sigma)[0]
-                bestindex = self.cands.index(best)
-                for k in reversed(range(ii, jj)):
-                    if k == bestindex:
+        cands = self.cands
+        kept = []
+        i = 0
+        while i < n:
+            head = int(order[i])                      # the candidate the run is measured from
+            j = i + 1                                 # first position (in frequency order) not yet looked at
+            while True:
+                # sorted by r, so whoever lies within r_err of `head` from j on is one stretch: a bisection
+                # finds about where it ends, the comparison itself (as the rule states it) says exactly
+                end = max(int(np.searchsorted(rs, r[head] + r_err, side="left")), j)
+                while end > j and not np.fabs(r[head] - rs[end - 1]) < r_err:
+                    end -= 1
+                while end < n and np.fabs(r[head] - rs[end]) < r_err:
+                    end += 1
+                if end == j:
+                    break
+                members = [head] + [int(k) for k in order[j:end]]
+                # largest sigma, then largest detected power, then first in the run
+                best = min(range(len(members)), key=lambda k: (-sig[members[k]], -ipw[members[k]]))
+                strongest = cands[members[best]]
+                for k in reversed(range(len(members))):
+                    if k == best:
                         continue
-                    match = self.cands[k]
-                    best.add_as_hit(match)
-                    match.note = "This candidate is a duplicate of %s:%d" % (best.filename, best.candnum)
-                    self.mark_as_duplicate(k)
+                    match = cands[members[k]]
+                    strongest.add_as_hit(match)
+                    match.note = "This candidate is a duplicate of %s:%d" % (strongest.filename, strongest.candnum)
+                    if self.trackdupes:
+                        self.duplicates.append(match)
                     if verbosity >= 2:
-                        print("Removing %s:%d (index: %d)" % (match.filename, match.candnum, k))
+                        print("Removing %s:%d (index: %d)" % (match.filename, match.candnum, len(kept) + k))
                         print("    %s" % match.note)
-                # the best one now sits at ii; look again, more may match it
-            else:
-                ii += 1
+                head, j = members[best], end
+            kept.append(head)
+            i = j
+        self.cands = [cands[k] for k in kept]
         if verbosity >= 1:
             print("Found %d candidates.\n" % self.get_numcands())
         self.cands.sort(key=_by_sigma)
 
+    # harmonic relations looked for besides the integer ones, as (numerator, denominator) of fund.f / harm.f
+    _RATIOS = ((3, 2), (5, 2), (2, 3), (4, 3), (5, 3), (3, 4), (5, 4), (2, 5), (3, 5), (4, 5))
+
     def remove_harmonics(self, verbosity=1):
-        """Drop the less significant of harmonically related candidates."""
-        numremoved = 0
+        """Going down the list by significance, whatever lies at an integer multiple or fraction (up to 16)
+        or at one of the small ratios of a stronger candidate's frequency goes."""
         self.cands.sort(key=_by_sigma)
-        if len(self.cands) < 2:
+        n = len(self.cands)
+        if n < 2:
             return
-        f_err = r_err / self.cands[0].T
+        cands = self.cands
+        _, f, _, _ = self._columns()
+        f_err = r_err / cands[0].T
         if verbosity >= 1:
             print("\nSearching for duplicate harmonics...")
-        ratios = list(zip([3.0, 5.0, 2.0, 4.0, 5.0, 3.0, 5.0, 2.0, 3.0, 4.0],
-                          [2.0, 2.0, 3.0, 3.0, 3.0, 4.0, 4.0, 5.0, 5.0, 5.0]))
-        ii = 0
+        ks = np.arange(1.0, 17.0)
+        ratio = np.array([float(a) / float(b) for a, b in self._RATIOS])
+        alive = np.ones(n, dtype=bool)
+        nalive, processed, fund, numremoved = n, 0, 0, 0
         while True:
-            fund = self.cands[ii]
-            jj = len(self.cands) - 1
-            while True:
-                harm = self.cands[jj]
-                harmstr = None
-                for factor in np.arange(1.0, 17.0):
-                    if np.fabs(fund.f - harm.f * factor) < f_err * factor:
-                        harmstr = "1/%dth" % factor
-                    elif np.fabs(fund.f - harm.f / factor) < f_err / factor:
-                        harmstr = ("%dnd" if factor == 2.0 else "%dth") % factor
-                    if harmstr:
-                        break
-                for numer, denom in ratios:
-                    factor = numer / denom
-                    if np.fabs(fund.f - harm.f * factor) < f_err * factor:
-                        harmstr = "%d/%dth" % (denom, numer)
-                        break
-                if harmstr:
-                    harm.note = ("This candidate (P=%.4f s, DM=%.2f) is a harmonic (%s) of %s:%d "
-                                 "(P=%.4f s, DM=%.2f)." % (harm.p, harm.DM, harmstr, fund.filename,
-                                                           fund.candnum, fund.p, fund.DM))
-                    numremoved += 1
-                    self.mark_as_bad(jj, "harmonic")
-                    if verbosity >= 2:
-                        print("Removing %s:%d (index: %d)" % (harm.filename, harm.candnum, jj))
-                        print("    %s" % harm.note)
-                jj -= 1
-                if jj == ii:
-                    break
-            ii += 1
-            if ii >= len(self.cands) - 1:
+            later = fund + 1 + np.flatnonzero(alive[fund + 1:])
+            fh = f[later][:, None]
+            # one row per weaker candidate, one column per factor: is harm.f * k (then harm.f / k) the fundamental's frequency?
+            below = np.fabs(f[fund] - fh * ks) < f_err * ks
+            above = np.fabs(f[fund] - fh / ks) < f_err / ks
+            whole = below | above
+            frac = np.fabs(f[fund] - fh * ratio) < f_err * ratio
+            for row in np.flatnonzero(whole.any(axis=1) | frac.any(axis=1))[::-1]:     # weakest first
+                jj = int(later[row])
+                if frac[row].any():                   # a ratio, if one fits, is what the note names
+                    numer, denom = self._RATIOS[int(np.argmax(frac[row]))]
+                    harmstr = "%d/%dth" % (denom, numer)
+                else:
+                    k = int(np.argmax(whole[row]))    # the smallest factor that fits
+                    harmstr = "1/%dth" % (k + 1) if below[row, k] else ("%dnd" if k == 1 else "%dth") % (k + 1)
+                harm, top = cands[jj], cands[fund]
+                harm.note = ("This candidate (P=%.4f s, DM=%.2f) is a harmonic (%s) of %s:%d "
+                             "(P=%.4f s, DM=%.2f)." % (harm.p, harm.DM, harmstr, top.filename, top.candnum, top.p, top.DM))
+                alive[jj] = False
+                nalive -= 1
+                numremoved += 1
+                if self.trackbad:
+                    self.badlists.setdefault("harmonic", []).append(harm)
+                if verbosity >= 2:
+                    print("Removing %s:%d (index: %d)" % (harm.filename, harm.candnum, processed + 1 + int(row)))
+                    print("    %s" % harm.note)
+            processed += 1
+            if processed >= nalive - 1:               # the last one left has nobody below it
                 break
+            fund = fund + 1 + int(np.argmax(alive[fund + 1:]))
+        self.cands = [c for c, ok in zip(cands, alive) if ok]
         if verbosity >= 1:
             print("Removed a total of %d harmonics.\n" % numremoved)
+
+    @staticmethod
+    def _dm_verdict(c, numdms, place, low_DM_cutoff):
+        """Why a candidate's hits over the DM trials do not look like a pulsar's, or None: (reason, note)."""
+        if len(c.hits) < numdms:
+            return "toofew", ("Candidate has only %d DM hits. This is less than minimum for 'good' cands "
+                              "(%d hits)" % (len(c.hits), numdms))
+        sigmas = np.array([h[2] for h in c.hits])
+        hitdm, _, hitsigma = c.hits[int(np.argmax(sigmas))]
+        if float(hitdm) <= low_DM_cutoff:
+            return "toolow", ("Hit with max sigma (%g) has dm (%.2f) <= low DM cutoff (%.2f) "
+                              % (hitsigma, hitdm, low_DM_cutoff))
+        if len(c.hits) > 1:
+            c.hits.sort(key=lambda h: float(h[0]))
+            where = np.array([place["%.2f" % h[0]] for h in c.hits])
+            if np.diff(where).min() > 1:
+                return "gaps", "DM list of hits has gaps (i.e. consecutive DMs don't have hits)."
+        return None
 
     def remove_DM_problems(self, numdms, dmlist, low_DM_cutoff, verbosity=1):
         """Drop candidates with fewer than numdms hits, whose strongest hit is at or below
         low_DM_cutoff, or whose hits are never at neighbouring DMs."""
         dms = np.unique([float(dm) for dm in dmlist])
-        dmdict = dict(zip(["%.2f" % dm for dm in dms], range(len(dms))))
-        counts = dict(toofew=0, toolow=0, gaps=0)
+        place = dict(("%.2f" % dm, i) for i, dm in enumerate(dms))     # a trial's position among the DMs searched
         self.cands.sort(key=_by_sigma)
-        for ii in reversed(range(len(self.cands))):
+        verdicts = [self._dm_verdict(c, numdms, place, low_DM_cutoff) for c in self.cands]
+        counts = dict(toofew=0, toolow=0, gaps=0)
+        for ii in reversed(range(len(self.cands))):   # (the rejects are listed weakest first)
+            if verdicts[ii] is None:
+                continue
             c = self.cands[ii]
-            why = None
-            if len(c.hits) < numdms:
-                why = "toofew"
-                c.note = ("Candidate has only %d DM hits. This is less than minimum for 'good' cands "
-                          "(%d hits)" % (len(c.hits), numdms))
-            else:
-                imax = int(np.argmax(np.array([hit[2] for hit in c.hits])))
-                hitdm, hitsnr, hitsigma = c.hits[imax]
-                if float(hitdm) <= low_DM_cutoff:
-                    why = "toolow"
-                    c.note = ("Hit with max sigma (%g) has dm (%.2f) <= low DM cutoff (%.2f) "
-                              % (hitsigma, hitdm, low_DM_cutoff))
-                elif len(c.hits) > 1:
-                    c.hits.sort(key=lambda h: float(h[0]))
-                    idx = np.asarray([dmdict["%.2f" % h[0]] for h in c.hits])
-                    if min(idx[1:] - idx[:-1]) > 1:
-                        why = "gaps"
-                        c.note = "DM list of hits has gaps (i.e. consecutive DMs don't have hits)."
-            if why:
-                counts[why] += 1
-                self.mark_as_bad(ii, "dmproblem")
-                if verbosity >= 2:
-                    print("Removing %s:%d (index: %d)" % (c.filename, c.candnum, ii))
-                    print("    %s" % c.note)
+            why, c.note = verdicts[ii]
+            counts[why] += 1
+            if self.trackbad:
+                self.badlists.setdefault("dmproblem", []).append(c)
+            if verbosity >= 2:
+                print("Removing %s:%d (index: %d)" % (c.filename, c.candnum, ii))
+                print("    %s" % c.note)
+        self.cands = [c for c, v in zip(self.cands, verdicts) if v is None]
         if verbosity >= 1:
             print("Removed %d candidates with DM problems.\n" % sum(counts.values()))
         if verbosity >= 2:
@@ -435,65 +477,62 @@ def _finish(cand):
     cand.ipow_det = opt_ipow
 
 
+_INF_N_RE = re.compile(r"^ Number of bins in the time series.*?(\S+)[ \t]*$", re.M)
+_INF_DT_RE = re.compile(r"^ Width of each time series bin \(sec\).*?(\S+)[ \t]*$", re.M)
+
+
+def _value(field):
+    """'123.45(6)' -> 123.45"""
+    return float(field.split("(")[0])
+
+
 def candlist_from_candfile(filename, trackbad=False, trackdupes=False):
-    """Parse one ACCEL text file (reference :1099-1200)."""
+    """One ACCEL text file as a Candlist (what the reference's parser, :1099-1200, makes of it).
+
+    The file is three parts: a table with one row per fundamental (rows begin with the candidate number in the
+    first column), a table of harmonics in blocks of `numharm` rows (the first row of a block begins with a blank
+    and the candidate number, the others with blanks only), and the .inf text, which holds N and dt.  Candidate
+    numbers are printed in four characters: from 10 000 on the column overflows and the numbers are counted on
+    from the last one read instead."""
     with open(filename, "r") as f:
-        lines = f.readlines()
-    numsamp = dt = None
-    for line in lines:
-        if line.startswith(" Number of bins in the time series"):
-            numsamp = int(line.split()[-1])
-        if line.startswith(" Width of each time series bin (sec)"):
-            dt = float(line.split()[-1])
-    tobs = numsamp * dt
+        text = f.read()
+    tobs = int(_INF_N_RE.findall(text)[-1]) * float(_INF_DT_RE.findall(text)[-1])
     DMstr = DM_re.search(filename).groups()[0]
-    cands, candnums = [], []
-    pending, pending_harm = None, 0
-    last_candnum = last_good = 0
-    for line in lines:
-        if fund_re.match(line):
-            s = line.split()
-            candnum = int(s[0])
-            if cands and len(s[0]) == 4 and cands[-1].candnum >= 9999:
-                candnum = last_candnum + 1
-            bin_ = float(s[7].split("(")[0])
-            z = float(s[9].split("(")[0])
-            cands.append(Candidate(candnum, float(s[1]), int(s[4]), float(s[2]), float(s[3]), bin_, z,
-                                   DMstr, filename, tobs))
-            candnums.append(candnum)
-            last_candnum = candnum
+    lines = text.split("\n")
+    # the fundamentals
+    cands, by_number = [], {}
+    for fields in (ln.split() for ln in lines if fund_re.match(ln)):
+        number = int(fields[0])
+        if cands and len(fields[0]) == 4 and cands[-1].candnum >= 9999:
+            number = cands[-1].candnum + 1
+        cand = Candidate(number, float(fields[1]), int(fields[4]), float(fields[2]), float(fields[3]), _value(fields[7]),
+                         _value(fields[9]), DMstr, filename, tobs)
+        cands.append(cand)
+        by_number.setdefault(number, cand)
+    # the harmonics: a block per candidate, as many rows as it has harmonics
+    last_done, at = 0, 0
+    while at < len(lines):
+        if not harms_re.match(lines[at]) or fund_re.match(lines[at]):
+            at += 1
             continue
-        if harms_re.match(line):
-            s = line.split()
-            candnum = int(s[0])
-            if len(s[0]) == 4 and last_good >= 9999:
-                candnum = last_good + 1
-            if candnum in candnums:
-                cand = cands[candnums.index(candnum)]
-                cand.harm_pows = np.zeros(cand.numharm, dtype=np.float64)
-                cand.harm_amps = np.zeros(cand.numharm, dtype=np.complex64)
-                power = parse_power(s[3])
-                phase = float(s[9].split("(")[0])
-                cand.harm_pows[0] = power
-                cand.harm_amps[0] = np.sqrt(power) * np.exp(phase * 1.0j)
-                if cand.numharm > 1:
-                    pending, pending_harm = cand, 1
-                else:
-                    last_good = candnum
-                    pending = None
-                    _finish(cand)
+        fields = lines[at].split()
+        number = int(fields[0])
+        if len(fields[0]) == 4 and last_done >= 9999:
+            number = last_done + 1
+        cand = by_number.get(number)
+        if cand is None:
+            at += 1
             continue
-        if pending is not None:
-            s = line.split()
-            power = parse_power(s[2])
-            phase = float(s[8].split("(")[0])
-            pending.harm_pows[pending_harm] = power
-            pending.harm_amps[pending_harm] = np.sqrt(power) * np.exp(phase * 1.0j)
-            pending_harm += 1
-            if pending_harm == pending.numharm:
-                _finish(pending)
-                last_good = pending.candnum
-                pending = None
+        # the block's rows as (power field, phase field): the first row carries the number in front
+        rows = [(fields[3], fields[9])] + [(p[2], p[8]) for p in (ln.split() for ln in lines[at + 1:at + cand.numharm])]
+        if len(rows) == cand.numharm:
+            power = np.array([parse_power(p) for p, _ in rows], dtype=np.float64)
+            phase = np.array([_value(q) for _, q in rows], dtype=np.float64)
+            cand.harm_pows = power
+            cand.harm_amps = (np.sqrt(power) * np.exp(phase * 1.0j)).astype(np.complex64)
+            _finish(cand)
+            last_done = number
+        at += max(cand.numharm, 1)
     return Candlist(cands, trackbad=trackbad, trackdupes=trackdupes)
 
 

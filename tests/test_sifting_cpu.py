@@ -152,3 +152,42 @@ def test_rogue_harmonic_and_power_cutoff(tmp_path):
     assert len(cl) == 1 and "All harmonics have power < 8" in cl.badlists["harmpowcutoff"][0].note
     cl.reject_rogueharmpow()
     assert len(cl) == 0 and "High-numbered harmonic (6)" in cl.badlists["rogueharmpow"][0].note
+
+
+def _frozen():
+    import importlib.util
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_sifting_frozen", os.path.join(here, "make_sifting_frozen.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with open(os.path.join(here, "sifting_frozen.json")) as f:
+        return mod, json.load(f), here
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15])
+def test_cross_dm_steps_reproduce_the_frozen_outputs(seed):
+    """Duplicates, harmonics, DM problems and the whole sequence on fixed synthetic lists (clusters, chains that
+    re-anchor on their strongest member, ties, integer and ratio harmonics, low-DM peaks, DM gaps): kept
+    candidates in order, their hits, duplicates and rejects in order, every note -- as frozen from this module
+    before its insides were rewritten (its own outputs: they pin nothing against the reference)."""
+    import json
+    mod, frozen, _ = _frozen()
+    got = mod.run_case(seed)
+    for step, desc in got.items():
+        if str(seed) in frozen["cases"]:
+            assert json.loads(json.dumps(desc)) == frozen["cases"][str(seed)][step], step
+        assert mod.digest(desc) == frozen["case_digests"][str(seed)][step], step
+
+
+def test_accel_file_parser_reproduces_the_frozen_outputs(tmp_path):
+    import json
+    mod, frozen, here = _frozen()
+    import os
+    small = mod.parsed_file(os.path.join(here, "post_small_DM7.50_ACCEL_30"))
+    assert json.loads(json.dumps(small)) == frozen["post_small_parsed"]
+    big = mod.parsed_file(mod.big_accel_file(str(tmp_path / "big_DM3.00_ACCEL_50")))     # candidate numbers past 9999
+    assert len(big) == frozen["big_file"]["count"] and [b[0] for b in big[9997:10002]] == [9998, 9999, 10000, 10001, 10002]
+    assert json.loads(json.dumps(big[9997:10002])) == frozen["big_file"]["around_9999"]
+    assert mod.digest(big) == frozen["big_file"]["digest"]
