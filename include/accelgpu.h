@@ -128,8 +128,8 @@ int accelgpu_synchronize(accelgpu_ctx *ctx);
  *                      exactly; -1: too many, the bounded sum ran over the whole plane instead)
  *   pf_list_cap    0   capacity of that list in entries (0: 1/64 of all there are)
  *   pf_limit_ppm 10000 entries per million (row, four columns) beyond which the list costs more than the
- *                      bounded sum over the whole plane it replaces; pf_sample 1: a sample of 2^17
- *                      (row, four columns) is asked before the walk (20 microseconds), and a list
+ *                      bounded sum over the whole plane it replaces; pf_sample 1: a sample of 2^15
+ *                      (row, four columns) is asked before the walk (30 microseconds), and a list
  *                      that would be longer is not started; pf_memory 1: a context whose list was
  *                      given up leaves the coarse bound out of its next 4 launches (8, 16 ... 64 when
  *                      the one after gives up again).  Read-only: "pf_last_listed" (the last

@@ -1543,8 +1543,8 @@ struct WorkItem {
 // any way out of the row loop, even a changed loop bound, costs the kernels 10 to 30 registers and with them
 // resident workgroups; and cutting the walk into shorter workgroups that report as they end multiplies a
 // fixed cost per workgroup that is a third of the whole (4, 8, 16 row chunks: 3.4, 5.7, 8.9 ms).  So the
-// question is asked BEFORE the walk: k_prefilter_sample works out the bound sums of a few hundred thousand
-// (row, group)s spread evenly over the plane (one per lane: 20 microseconds), its last workgroup scales the
+// question is asked BEFORE the walk: k_prefilter_sample works out the bound sums of some tens of thousands of
+// (row, group)s spread evenly over the plane (one per lane: 30 microseconds), its last workgroup scales the
 // count to the whole plane and raises the flag if the list would be longer than `limit`, and the walk's
 // workgroups look at the flag when they begin.
 constexpr int kPfLcap = 2048; // entries of a workgroup's own list in LDS
@@ -1902,9 +1902,10 @@ __global__ __launch_bounds__(256) void k_prefilter_pairs(
 
 // How long would the list be?  Asked before the walk (see the note on the control words): every lane takes one
 // (row, group) -- sample k of nsamples: group k * gstep mod ngroups, gstep odd and near the golden section of
-// ngroups, so that the samples are spread evenly over the columns; row a multiplicative hash of k -- and works
-// out its bound sums exactly as k_prefilter_lanes does for that row.  The last workgroup to finish scales the
-// count: more than sample_limit of the samples listed, and the flag goes up.
+// ngroups, so that the samples are spread evenly over the columns; one row per wave, the waves going round the
+// rows, so that a wave reads each source row's address once -- and works out its bound sums exactly as
+// k_prefilter_lanes does for that row.  The last workgroup to finish scales the count: more than sample_limit of
+// the samples listed, and the flag goes up.
 template <int NSTAGES>
 __global__ __launch_bounds__(256) void k_prefilter_sample(
     const unsigned short *__restrict__ mx, int numz, GroupGrid g, int64_t ngroups, const int64_t *__restrict__ rowmx,
@@ -1924,7 +1925,7 @@ __global__ __launch_bounds__(256) void k_prefilter_sample(
     const unsigned int k = blockIdx.x * 256 + threadIdx.x;
     const bool live = k < nsamples;
     const uint32_t gl = group0 + (uint32_t) (((uint64_t) (live ? k : 0u) * gstep) % (uint64_t) ngroups);
-    const int zi = (int) ((((live ? k : 0u) * 2654435761u) >> 8) % (uint32_t) numz);
+    const int zi = __builtin_amdgcn_readfirstlane((int) ((k >> 6) % (uint32_t) numz));
     const uint32_t sb = gl / (uint32_t) kGpb;
     const int lg = (int) (gl % (uint32_t) kGpb);
     const int lfirst = max(4 * lg - g.a, 0), llast = min(4 * lg - g.a + 3, kUseLen - 1);

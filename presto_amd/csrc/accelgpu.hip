@@ -834,9 +834,9 @@ int launch_prefilter(accelgpu_ctx *ctx, int nstages, const accelk::HarmParams &p
     const double all_entries = (double) ctx->numz * (double) ngroups;
     if (ctx->tune.hs_bound != 4) // (forced: as long a list as there is room for)
         wcap = (unsigned int) std::min<double>((double) wcap, std::max(1.0, all_entries * 1e-6 * std::max(ctx->tune.pf_limit_ppm, 0)));
-    // ... by asking a sample of the (row, group)s before the walk (k_prefilter_sample): 2^17 of them put the list's
-    // length within a few per cent where it matters (a list at the limit has hundreds of them), in 20 microseconds
-    const unsigned int nsamples = (unsigned int) std::min<double>(131072.0, all_entries);
+    // ... by asking a sample of the (row, group)s before the walk (k_prefilter_sample): 2^15 of them put the list's
+    // length within a few per cent where it matters (a list at the limit has hundreds of them)
+    const unsigned int nsamples = (unsigned int) std::min<double>(32768.0, all_entries);
     unsigned int gstep = (unsigned int) ((double) ngroups * 0.6180339887) | 1u;
     const unsigned int sample_limit = (unsigned int) std::min<double>(4294967295.0, std::ceil((double) wcap * (double) nsamples / all_entries));
 #define LAUNCH_PF(NS)                                                                                          \
