@@ -413,14 +413,17 @@ template <class P> struct PairStore {
     __device__ __forceinline__ PairStore(int t, int shift, bool halves, bool maxima = false)
     {
         col0 = 2 * t - shift;
+        // (a group's two lanes hold the same maximum: the odd one's offsets lie far outside the block's run, so
+        // that the range check drops its stores)
+        const int odd = (t & 1) ? 0x40000000 : 0;
 #pragma unroll
         for (int f = 0; f < NEARF; f++) {
-            nearm[f] = maxima ? 2 * (((2 * t + STEP * f) >> 2) - (shift >> 2)) : 0;
+            nearm[f] = maxima ? (2 * (((2 * t + STEP * f) >> 2) - (shift >> 2))) | odd : 0;
             asm("" : "+v"(nearm[f]));
         }
 #pragma unroll
         for (int g = 0; g < NGM; g++) {
-            grpm[g] = maxima ? 2 * (((2 * t + STEP * (NEARF + GM * g)) >> 2) - (shift >> 2)) : 0;
+            grpm[g] = maxima ? (2 * (((2 * t + STEP * (NEARF + GM * g)) >> 2) - (shift >> 2))) | odd : 0;
             asm("" : "+v"(grpm[g]));
         }
         const int c0 = 2 * t - shift; // column of the thread's first pair
@@ -450,18 +453,22 @@ template <class P> struct PairStore {
     }
     // The largest upper half of the four outputs n >> 2 == const that this lane and its neighbour
     // (lane ^ 1) hold, into the plane of group maxima; outputs outside the block's columns do not count.
-    __device__ __forceinline__ void maxima(__amdgpu_buffer_rsrc_t mx, int f, float p0, float p1, int ncols) const
+    template <int f> __device__ __forceinline__ void maxima(__amdgpu_buffer_rsrc_t mx, float p0, float p1, int ncols) const
     {
         float m = fmaxf(p0, p1);
         if (f < NEARF || STEP * (f + 1) > kUseLen) // pairs that can lie before or behind the block's columns
             m = (unsigned int) (col0 + STEP * f) < (unsigned int) ncols ? m : 0.f;
-        const float o = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0xB1, 0xF, 0xF, true)); // lane ^ 1
-        m = fmaxf(m, o);
-        const unsigned short h = (unsigned short) (__float_as_uint(m) >> 16);
-        if (f < NEARF)
-            __builtin_amdgcn_raw_buffer_store_b16(h, mx, nearm[f], 0, 0);
+        // max(m, m of lane ^ 1) as one instruction.  (Through fmaxf and a DPP move the compiler spends three: the
+        // move, a canonicalising max of the moved value with itself, the max.  The wait states a DPP read of a
+        // register just written needs are spelled out, since the hazard check does not look inside.)
+        asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(m) : "v"(m));
+        // the upper half goes out as it stands in the register (no shift): the store that takes bits 16..31.  Nothing
+        // in the kernel reads these bytes back, so the compiler needs to know no more than that the store happens.
+        if constexpr (f < NEARF)
+            asm volatile("buffer_store_short_d16_hi %0, %1, %2, 0 offen" ::"v"(m), "v"(nearm[f]), "s"(mx));
         else
-            __builtin_amdgcn_raw_buffer_store_b16(h, mx, grpm[(f - NEARF) / GM] + (STEP / 2) * ((f - NEARF) % GM), 0, 0);
+            asm volatile("buffer_store_short_d16_hi %0, %1, %2, 0 offen offset:%3" ::"v"(m), "v"(grpm[(f - NEARF) / GM]), "s"(mx),
+                         "n"((STEP / 2) * ((f - NEARF) % GM)));
     }
     __device__ __forceinline__ void refresh(bool halves)
     {
@@ -746,15 +753,15 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
         if constexpr (PAIR) {
             afft::fft3x<P, +1, SER, true>(
                 lds, load, tw1, tw2, mid,
-                [&](int n, c32 v, c32 w) {
-                    const int f = (n - 2 * t) / (P::R1 * P::R2);
+                [&](auto fc, c32 v, c32 w) {
+                    constexpr int f = decltype(fc)::value;
                     const float p0 = power_of(v), p1 = power_of(w);
                     if constexpr (SPLIT)
                         put2.split(rsrc_hi, rsrc_lo, f, p0, p1);
                     else
                         put2.powers(rsrc, f, p0, p1);
                     if constexpr (MAXIMA)
-                        put2.maxima(rsrc_mx, f, p0, p1, ncols);
+                        put2.template maxima<f>(rsrc_mx, p0, p1, ncols);
                 },
                 stamp);
         } else {

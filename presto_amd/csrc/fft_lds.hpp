@@ -307,7 +307,18 @@ struct NoStamp {
 
 // PAIR (plans with two pass-3 butterflies per thread): the thread takes butterflies 2t and 2t + 1
 // instead of t and t + NT, so that it owns outputs n and n + 1 for n = 2t + R1*R2*f, and
-// store(n, v, w) receives both: the caller can store them as one wider access.
+// store(PairIndex<f>(), v, w) receives both: the caller can store them as one wider access, and
+// f can be used where the instruction needs an immediate.
+template <int F> struct PairIndex {
+    static constexpr int value = F;
+};
+template <int F, int NF, class Store> __device__ __forceinline__ void pair_loop(Store &store, const c32 *v)
+{
+    if constexpr (F < NF) {
+        store(PairIndex<F>(), v[F], v[NF + F]);
+        pair_loop<F + 1, NF>(store, v);
+    }
+}
 template <class P, int DIR, int SER = 0, bool PAIR = false, class Load, class Tw1, class Tw2, class Mid,
           class Store, class Stamp = NoStamp>
 __device__ __forceinline__ void fft3x(c32 *lds, Load load, Tw1 tw1, Tw2 tw2, Mid mid, Store store,
@@ -375,9 +386,8 @@ __device__ __forceinline__ void fft3x(c32 *lds, Load load, Tw1 tw1, Tw2 tw2, Mid
 #pragma unroll
         for (int u = 0; u < 2; u++)
             Dft<P::R3, DIR, SER>::run(&v[u * P::R3]);
-#pragma unroll
-        for (int f = 0; f < P::R3; f++)
-            store(2 * t + P::R1 * P::R2 * f, v[f], v[P::R3 + f]);
+        // (the pair's index f reaches the caller as a compile-time constant: PairIndex<f>)
+        pair_loop<0, P::R3>(store, v);
     } else {
 #pragma unroll
         for (int u = 0; u < P::B3; u++) {
