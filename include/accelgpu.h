@@ -116,10 +116,11 @@ int accelgpu_synchronize(accelgpu_ctx *ctx);
  *                      fetching the lower halves wherever a bound sum crosses a threshold: the
  *                      same hits from half the bytes.  On large planes searched with 2 to 16
  *                      harmonics (8192-point transforms) a coarser bound runs in front: plane
- *                      generation also writes the largest upper half of every four columns, the
- *                      sums of those single out the few (row, four columns) that could cross a
- *                      threshold, and only these are summed (exactly): the same hits again, from
- *                      an eighth of the bytes.  0: float plane and float sums; 2 / 3: the bounded
+ *                      generation also writes the largest upper half of every eight columns, in
+ *                      steps of four; sums of those (and, for harmonics up to 1/4, of the source
+ *                      cells' own upper halves) single out the few (row, four columns) that could
+ *                      cross a threshold, and only these are summed (exactly): the same hits again,
+ *                      from an eighth of the bytes.  0: float plane and float sums; 2 / 3: the bounded
  *                      sum alone with one / several columns per lane; 4: the coarse bound wherever
  *                      it can run.  Changing between 0 and the others sets the search up afresh
  *                      (an empty plane).  Read-only: "hs_bound_active" (1 if the current search
@@ -136,10 +137,10 @@ int accelgpu_synchronize(accelgpu_ctx *ctx);
  *                      COLLECTED launch: entries listed, -1 given up, -2 the coarse bound did not
  *                      run), "pf_skip" (launches still to go without it).  hs_bound 4 ignores the
  *                      limit and the memory.
- *   pf_pairs       1   with up to 8 harmonics the coarse bound's kernel gives a lane two adjacent
- *                      groups of four columns (one 8-byte load per source and lane instead of four
- *                      16-bit loads); 2: with 16 harmonics too; 3: the 8-byte loads with one group
- *                      per lane; 0: never
+ *   pf_groups      0   groups of four columns a lane of the coarse bound's kernel takes: 0 two with up
+ *                      to 8 harmonics and one with 16 (two cost it its waves); 1 / 2: always that many
+ *   pf_nt          0   threads per workgroup of that kernel: 0 by the size of the search (1024 where
+ *                      that still makes several workgroups per CU); 256 / 512 / 1024: that many
  *   hits_cap   2^20    records in each device hit buffer (set: reallocates both; they
  *                      grow on their own when a search overflows them)
  * ref: none (the reference's only run-time knob is -ncpus). */

@@ -404,28 +404,14 @@ template <class P> struct PairStore {
     static constexpr int G4 = 4096 / (4 * STEP) > 0 ? 4096 / (4 * STEP) : 1; // f's per offset register, powers
     static constexpr int G2 = 4096 / (2 * STEP) > 0 ? 4096 / (2 * STEP) : 1; // f's per offset register, 16-bit planes
     static constexpr int NG4 = (NF - NEARF + G4 - 1) / G4, NG2 = (NF - NEARF + G2 - 1) / G2;
-    static constexpr int GM = 4096 / (STEP / 2) > 0 ? 4096 / (STEP / 2) : 1; // f's per offset register, group maxima
-    static constexpr int NGM = (NF - NEARF + GM - 1) / GM;
     int near4[NEARF], grp4[NG4 > 0 ? NG4 : 1];
     int near2[NEARF], grp2[NG2 > 0 ? NG2 : 1];
-    int nearm[NEARF], grpm[NGM > 0 ? NGM : 1]; // byte offsets of the pairs' groups of four (n >> 2) in a block's run of maxima
-    int col0;                                  // column of the thread's first pair
+    int col0;  // column of the thread's first pair
+    int gslot; // the first pair's group of four (n >> 2) among the transform's
     __device__ __forceinline__ PairStore(int t, int shift, bool halves, bool maxima = false)
     {
         col0 = 2 * t - shift;
-        // (a group's two lanes hold the same maximum: the odd one's offsets lie far outside the block's run, so
-        // that the range check drops its stores)
-        const int odd = (t & 1) ? 0x40000000 : 0;
-#pragma unroll
-        for (int f = 0; f < NEARF; f++) {
-            nearm[f] = maxima ? (2 * (((2 * t + STEP * f) >> 2) - (shift >> 2))) | odd : 0;
-            asm("" : "+v"(nearm[f]));
-        }
-#pragma unroll
-        for (int g = 0; g < NGM; g++) {
-            grpm[g] = maxima ? (2 * (((2 * t + STEP * (NEARF + GM * g)) >> 2) - (shift >> 2))) | odd : 0;
-            asm("" : "+v"(grpm[g]));
-        }
+        gslot = maxima ? t >> 1 : 0;
         const int c0 = 2 * t - shift; // column of the thread's first pair
 #pragma unroll
         for (int f = 0; f < NEARF; f++) {
@@ -445,15 +431,11 @@ template <class P> struct PairStore {
             asm("" : "+v"(grp2[g]));
         }
     }
-    __device__ __forceinline__ void refresh_maxima()
-    {
-#pragma unroll
-        for (int g = 0; g < NGM; g++)
-            asm volatile("" : "+v"(grpm[g]));
-    }
     // The largest upper half of the four outputs n >> 2 == const that this lane and its neighbour
-    // (lane ^ 1) hold, into the plane of group maxima; outputs outside the block's columns do not count.
-    template <int f> __device__ __forceinline__ void maxima(__amdgpu_buffer_rsrc_t mx, float p0, float p1, int ncols) const
+    // (lane ^ 1) hold, into the workgroup's table of the transform's group maxima in LDS (both lanes write the
+    // same value to the same place); outputs outside the block's columns do not count.  What goes to the plane
+    // of maxima is formed from this table once the whole transform has written it: see window_maxima().
+    template <int f> __device__ __forceinline__ void maxima(unsigned short *gmx, float p0, float p1, int ncols) const
     {
         float m = fmaxf(p0, p1);
         if (f < NEARF || STEP * (f + 1) > kUseLen) // pairs that can lie before or behind the block's columns
@@ -462,13 +444,7 @@ template <class P> struct PairStore {
         // move, a canonicalising max of the moved value with itself, the max.  The wait states a DPP read of a
         // register just written needs are spelled out, since the hazard check does not look inside.)
         asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(m) : "v"(m));
-        // the upper half goes out as it stands in the register (no shift): the store that takes bits 16..31.  Nothing
-        // in the kernel reads these bytes back, so the compiler needs to know no more than that the store happens.
-        if constexpr (f < NEARF)
-            asm volatile("buffer_store_short_d16_hi %0, %1, %2, 0 offen" ::"v"(m), "v"(nearm[f]), "s"(mx));
-        else
-            asm volatile("buffer_store_short_d16_hi %0, %1, %2, 0 offen offset:%3" ::"v"(m), "v"(grpm[(f - NEARF) / GM]), "s"(mx),
-                         "n"((STEP / 2) * ((f - NEARF) % GM)));
+        gmx[gslot + (STEP / 4) * f] = (unsigned short) (__float_as_uint(m) >> 16);
     }
     __device__ __forceinline__ void refresh(bool halves)
     {
@@ -506,6 +482,59 @@ template <class P> struct PairStore {
         }
     }
 };
+
+// An entry of the plane of maxima for the largest upper half h of its columns: h + 1, which as the upper half of a
+// float is greater than every power with upper half <= h (the bound the sums work with: see bound_value), so that
+// readers need no arithmetic; 0xffff (a NaN either way) stays.
+__device__ __forceinline__ unsigned short bound_entry(unsigned int h) { return (unsigned short) (h + (h < 0xffffu ? 1u : 0u)); }
+
+// The plane of maxima holds, per entry, the largest upper half of a WINDOW of two consecutive groups of four
+// outputs: entry j of a block stands for the groups j and j + 1 (up to eight columns), so that any run of up to
+// five consecutive columns is bounded by ONE entry -- the one its first column's group has (see the coarse bound
+// in front of the harmonic sum).  A thread holds the maxima of its own groups only, and a group's neighbour may
+// sit in another wave, so the transform's group maxima go through a table in LDS (4 KB, behind the FFT image;
+// two entries of padding, kept zero): written during the last pass, read here after the barrier that ends the
+// transform -- thread t forms the windows of the groups 2t, 2t + 1 (or 2t + 1, 2t + 2), the same 2 * NT on, ...
+// and stores them, consecutive threads to consecutive pairs of entries.  `s4` = shift >> 2: plane entry j is the transform's group j + s4; entries before the
+// block's first group and after its last are dropped by the descriptor's range check.  The block's last
+// windows (they reach into the next block) are completed by k_group_fix.
+// (two entries at a time: the table read as 32-bit words, the two maxima and the two increments each one packed
+// instruction, one 4-byte store; which pairs are aligned in the plane depends on the parity of s4)
+template <class P, int J, bool ODD>
+__device__ __forceinline__ void window_maxima_one(const uint32_t *gmx32, __amdgpu_buffer_rsrc_t rs, int t, int o0, int o1)
+{
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    constexpr int NP = P::N / 8; // pairs of groups
+    if constexpr (J < NP / P::NT) {
+        const int pidx = t + P::NT * J;
+        const uint32_t d0 = gmx32[pidx], d1 = gmx32[pidx + 1];   // groups 2p, 2p + 1 | 2p + 2, 2p + 3
+        const uint32_t mid = __builtin_amdgcn_alignbit(d1, d0, 16); // groups 2p + 1, 2p + 2
+        // windows 2p, 2p + 1 (even s4) or 2p + 1, 2p + 2 (odd)
+        us2 w = __builtin_elementwise_max(__builtin_bit_cast(us2, ODD ? mid : d0), __builtin_bit_cast(us2, ODD ? d1 : mid));
+        w = __builtin_elementwise_add_sat(w, us2{1, 1}); // (bound_entry of both)
+        if constexpr (J == 0)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), rs, o0, 0, 0);
+        else
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, w), rs, o1 + 4 * P::NT * (J - 1), 0, 0); // (the constant becomes the instruction's offset field)
+        window_maxima_one<P, J + 1, ODD>(gmx32, rs, t, o0, o1);
+    }
+}
+template <class P> __device__ __forceinline__ void window_maxima(const unsigned short *gmx, unsigned short *out_mx, int t, int s4)
+{
+    static_assert((P::N / 8) % P::NT == 0, "pairs of groups divide evenly among the threads");
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out_mx, 0, kGpb * 2, 0x00020000);
+    const uint32_t *gmx32 = reinterpret_cast<const uint32_t *>(gmx);
+    // the first store's offset can be negative (groups before the block's first column), the others cannot:
+    // a register each, so that a negative offset reaches the range check as a large unsigned number
+    const int odd = s4 & 1;
+    int o0 = 2 * (2 * t + odd - s4), o1 = 2 * (2 * (t + P::NT) + odd - s4);
+    asm("" : "+v"(o0), "+v"(o1));
+    if (odd)
+        window_maxima_one<P, 0, true>(gmx32, rs, t, o0, o1);
+    else
+        window_maxima_one<P, 0, false>(gmx32, rs, t, o0, o1);
+}
+constexpr int kMaximaLdsBytes = 2 * (8192 / 4 + 2); // the table above for the 8192-point plan
 
 // ---------------------------------------------------------------------------
 // Correlation: one workgroup per (template z, chunk of blocks).  The template's
@@ -688,6 +717,13 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
         for (int a = 0; a < H; a++)
             dreg[a] = D[P::M1 * a + t];
     }
+    // MAXIMA: the transform's group maxima in LDS (see window_maxima), and where the previous transform's go
+    unsigned short *gmx = reinterpret_cast<unsigned short *>(smem + P::LDS_BYTES);
+    unsigned short *mx_prev = nullptr;
+    if constexpr (MAXIMA) {
+        if (t < 2)
+            gmx[P::N / 4 + t] = 0; // the padding entries (visible after the first transform's barriers)
+    }
 
     for (int it = b0; it < b1; it++) {
         stamp.begin(it - b0);
@@ -703,9 +739,6 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
         // MAXIMA: the block's run of the plane of group maxima in row z (the launch covers the whole block grid:
         // a block's index is its place in that plane)
         unsigned short *out_mx = MAXIMA ? mx + (size_t) (ZL ? it : z) * (size_t) mxlen + (size_t) blk * kGpb : nullptr;
-        const __amdgpu_buffer_rsrc_t rsrc_mx = __builtin_amdgcn_make_buffer_rsrc(out_mx, 0, MAXIMA ? kGpb * 2 : 0, 0x00020000);
-        if constexpr (MAXIMA)
-            put2.refresh_maxima();
         if constexpr (PAIR)
             put2.refresh(SPLIT);
         else if constexpr (SPLIT)
@@ -749,6 +782,12 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
                 for (int a = 0; a < H; a++)
                     dreg[a] = D[P::M1 * a + t];
             }
+            // the previous transform's maxima: its table is complete (the barrier that ended it) and is not
+            // written again before this transform's last pass, three barriers on
+            if constexpr (MAXIMA) {
+                if (mx_prev)
+                    window_maxima<P>(gmx, mx_prev, t, shift >> 2);
+            }
         };
         if constexpr (PAIR) {
             afft::fft3x<P, +1, SER, true>(
@@ -761,7 +800,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
                     else
                         put2.powers(rsrc, f, p0, p1);
                     if constexpr (MAXIMA)
-                        put2.template maxima<f>(rsrc_mx, p0, p1, ncols);
+                        put2.template maxima<f>(gmx, p0, p1, ncols);
                 },
                 stamp);
         } else {
@@ -778,6 +817,11 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
         }
         __syncthreads();
         stamp(9);
+        mx_prev = out_mx;
+    }
+    if constexpr (MAXIMA) {
+        if (mx_prev)
+            window_maxima<P>(gmx, mx_prev, t, shift >> 2);
     }
 }
 
@@ -1454,24 +1498,33 @@ __global__ __launch_bounds__(256) void k_harmsum_bl(
 }
 
 // ---------------------------------------------------------------------------
-// A coarser bound in front of the sums: the largest upper half of every group of four
-// consecutive columns, and the harmonic sum of those.
+// A coarser bound in front of the sums: the largest upper half of every eight consecutive columns, in steps of
+// four, and the harmonic sum of those.
 //
-// The groups follow the transforms that wrote the plane: within a block, output n of the
-// transform (column blk_col + n - shift) belongs to group n >> 2.  The plane of maxima has
-// kGpb = 1868 16-bit entries per block and row, entry (b, g) for the columns l = n - shift of
-// block b with (l + A) >> 2 == g, A = shift & 3.  A block of 7470 columns ends (A = 0) or begins
-// (A = 2) with a group of two columns; that entry and its neighbour in the block both stand for
-// the six columns together, so that any run of up to five consecutive columns -- whatever block
-// boundary it crosses -- lies within two consecutive entries.
+// The groups follow the transforms that wrote the plane: within a block, output n of the transform (column
+// blk_col + n - shift) belongs to group n >> 2.  The plane of maxima has kGpb = 1868 16-bit entries per block
+// and row; entry (b, g) stands for the WINDOW of the groups g and g + 1 of block b, i.e. the columns l = n - shift
+// with (l + A) >> 2 in {g, g + 1}, A = shift & 3 -- eight columns, fewer where a block begins (A = 2) or ends
+// (A = 0) with a group of two -- and holds their largest upper half plus one (bound_entry): shifted up 16 bits
+// that is the float the sums use as the bound.  The windows of a block's last two entries reach over the next block's first two
+// groups (k_group_fix sees to that after plane generation).  So any run of up to five consecutive columns,
+// whatever block boundary it crosses, lies within the window of ONE entry: that of the group its first column
+// is in.
 //
-// k_prefilter gives a lane one group of four fundamental columns.  For harmonic h/2^s the source
-// columns of those four lie within five consecutive columns, so the larger of two consecutive
-// entries is an upper bound for the source cell of each of the four, and -- floating-point
-// addition being monotonic -- the sums of these bounds, taken in the reference's order, bound
-// every stage's sum of every one of the four columns.  A (row, group) whose bound sums stay at or
-// below the thresholds has no crossing; the others are written to a list, and k_flagged_exact
-// sums their columns exactly from both halves.
+// k_prefilter_lanes gives a lane one group of four fundamental columns (or two, 256 groups apart).  For harmonic
+// h/2^s the source columns of those four lie within five consecutive columns, so one entry of the source's row is
+// an upper bound for the source cell of each of the four, and -- floating-point addition being monotonic -- the
+// sums of these bounds, taken in the reference's order, bound every stage's sum of every one of the four columns.
+// A (row, group) whose bound sums stay at or below the thresholds has no crossing; the others are written to a
+// list, and k_flagged_exact sums their columns exactly from both halves.
+//
+// Harmonics up to 1/4 take their bound from the plane of upper halves itself: the source cells of four
+// consecutive columns are then at most two cells, the larger of which is a far tighter bound than a window of
+// eight, and these sources move to a new row so rarely (once in 4 to 16 rows) that their two loads cost little.
+// That tightness is what lets everything else -- the group's own entry and the sources above 1/4 -- do with one
+// load from the windows: windows throughout list over 1 % of the (row, group)s of a 16-harmonic search in noise,
+// this mixture 0.1 %, as few as the maxima of single groups did at two loads per source (the kernel is bound by
+// the number of its load instructions).
 // ---------------------------------------------------------------------------
 struct GroupGrid {
     int64_t prepop_col0; // first column of the first block below the search region
@@ -1488,8 +1541,32 @@ __device__ __forceinline__ uint32_t group_entry_of(const GroupGrid &g, uint32_t 
     const uint32_t b = (srch ? (uint32_t) g.nprepop : 0u) + x / (uint32_t) kUseLen, l = x % (uint32_t) kUseLen;
     return b * (uint32_t) kGpb + ((l + (uint32_t) g.a) >> 2);
 }
+// Does harmonic h/2^s take its bound from the cells (true) or from the windows?
+__host__ __device__ constexpr bool pf_from_cells(int s, int h) { return 4 * h <= (1 << s); }
+// Where the bound of harmonic h/2^s for the fundamental columns cf..cl (at most four consecutive ones) is read,
+// as a byte offset within the source's row: of the first source cell in the plane of upper halves, bit 0 set if
+// the second cell is the next one (from cells); or of the entry of the first source column's group in the plane
+// of maxima (from windows).  false: not bounded that way (a source below the plane's first block, a run across
+// the gap between the blocks below the search region and the search blocks) -- such a group is always listed.
+__device__ __forceinline__ bool source_offset(const GroupGrid &g, uint32_t cf, uint32_t cl, int s, int h, uint32_t &off)
+{
+    const uint32_t s0 = (uint32_t) (((uint64_t) cf * h + (1u << (s - 1))) >> s), s1 = (uint32_t) (((uint64_t) cl * h + (1u << (s - 1))) >> s);
+    if (pf_from_cells(s, h)) {
+        off = 2u * s0 + (s1 > s0 ? 1u : 0u);
+        return s1 - s0 <= 1u;
+    }
+    off = 0;
+    if (s0 < (uint32_t) g.prepop_col0)
+        return false;
+    const uint32_t e0 = group_entry_of(g, s0);
+    const uint32_t d = group_entry_of(g, s1) - e0;
+    off = 2u * e0;
+    // the next entry's group is in the window; from a block's last two entries on, so are the next block's first two
+    return d <= 1 || (d == 2 && e0 % (uint32_t) kGpb >= (uint32_t) kGpb - 2);
+}
 
-// The plane of maxima from the plane of upper halves: one thread per entry.
+// The plane of maxima from the plane of upper halves (a host has written into the plane, or plane generation
+// did not keep the maxima): one thread per entry, its window straight from the cells.
 __global__ __launch_bounds__(256) void k_group_max(const unsigned short *__restrict__ hi, int64_t rlen,
                                                    const int64_t *__restrict__ blk_col, const int *__restrict__ blk_ncols,
                                                    GroupGrid g, unsigned short *__restrict__ mx)
@@ -1497,40 +1574,34 @@ __global__ __launch_bounds__(256) void k_group_max(const unsigned short *__restr
     constexpr unsigned int per_block = (kGpb + 255) / 256;
     const int lg = (int) (blockIdx.x % per_block) * 256 + threadIdx.x;
     const int b = (int) (blockIdx.x / per_block), zi = blockIdx.z;
-    const unsigned short *cells = hi + (size_t) zi * (size_t) rlen + blk_col[b];
+    if (lg >= kGpb)
+        return;
+    const unsigned short *row = hi + (size_t) zi * (size_t) rlen;
+    const unsigned short *cells = row + blk_col[b];
     const int ncols = min(blk_ncols[b], kUseLen);
-    const bool in = lg < kGpb;
-    unsigned int own = 0;
-    if (in) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int l = 4 * lg - g.a + j;
-            if (l >= 0 && l < ncols)
-                own = max(own, (unsigned int) cells[l]);
-        }
+    unsigned int w = 0;
+    for (int l = max(4 * lg - g.a, 0); l < min(4 * lg - g.a + 8, ncols); l++) // the groups lg and lg + 1
+        w = max(w, (unsigned int) cells[l]);
+    if (lg >= kGpb - 2 && b + 1 < g.nblk) { // ... and, from the block's last two entries, the next block's groups 0 and 1
+        const unsigned short *next = row + blk_col[b + 1];
+        for (int l = 0; l < min(8 - g.a, min(blk_ncols[b + 1], kUseLen)); l++)
+            w = max(w, (unsigned int) next[l]);
     }
-    // the six-column pair: both of its entries are neighbours within one wave (entries 0, 1 or 1866, 1867)
-    const int short_g = g.a == 0 ? kGpb - 1 : 0, partner = g.a == 0 ? kGpb - 2 : 1;
-    const unsigned int up = __shfl_down(own, 1), down = __shfl_up(own, 1);
-    if (lg == min(short_g, partner))
-        own = max(own, up);
-    else if (lg == max(short_g, partner))
-        own = max(own, down);
-    if (in)
-        mx[(size_t) zi * (size_t) g.mxlen + (size_t) b * kGpb + lg] = (unsigned short) own;
+    mx[(size_t) zi * (size_t) g.mxlen + (size_t) b * kGpb + lg] = bound_entry(w);
 }
 
-// After plane generation has written the maxima of the groups n >> 2: a block's two-column group and
-// its neighbour in the block both get the maximum of their six columns.
+// After plane generation has written the windows within every block: the windows of a block's last two
+// entries also take in the next block's first entry (its groups 0 and 1).  That entry is not changed here, so
+// the order in which the blocks are visited does not matter.
 __global__ __launch_bounds__(256) void k_group_fix(unsigned short *__restrict__ mx, GroupGrid g, int numz)
 {
     const int b = blockIdx.x * 256 + threadIdx.x, zi = blockIdx.y;
-    if (b >= g.nblk)
+    if (b + 1 >= g.nblk)
         return;
-    unsigned short *e = mx + (size_t) zi * (size_t) g.mxlen + (size_t) b * kGpb + (g.a == 0 ? kGpb - 2 : 0);
-    const unsigned short m = max(e[0], e[1]);
-    e[0] = m;
-    e[1] = m;
+    unsigned short *e = mx + (size_t) zi * (size_t) g.mxlen + (size_t) b * kGpb + (kGpb - 2);
+    const unsigned short nx = e[2]; // entry 0 of block b + 1
+    e[0] = max(e[0], nx);
+    e[1] = max(e[1], nx);
 }
 
 struct WorkItem {
@@ -1612,6 +1683,7 @@ __device__ __forceinline__ void pf_insert(PfShared &sh, unsigned long long mask,
 // The workgroup's list goes to the global one (after the barrier that ends the walk).  Whether it goes is
 // decided by one thread: the flag can change between two threads' looks at it, and there is a barrier below.
 constexpr unsigned int kPfNoBase = 0xFFFFFFFFu;
+template <int NT = 256>
 __device__ __forceinline__ void pf_flush(PfShared &sh, WorkItem *__restrict__ work, unsigned int *__restrict__ ctl, unsigned int limit)
 {
     const unsigned int n = min(sh.ln, (unsigned int) kPfLcap);
@@ -1630,15 +1702,19 @@ __device__ __forceinline__ void pf_flush(PfShared &sh, WorkItem *__restrict__ wo
     const unsigned int base = sh.gbase;
     if (base == kPfNoBase)
         return;
-    for (unsigned int i = threadIdx.x; i < n; i += 256)
+    for (unsigned int i = threadIdx.x; i < n; i += NT)
         work[base + i] = sh.lst[i];
 }
-template <int NSTAGES>
-__global__ __launch_bounds__(256) void k_prefilter_lanes(
-    const unsigned short *__restrict__ mx, int numz, GroupGrid g, int64_t ngroups,
-    const int64_t *__restrict__ rowmx /*[numz][NHS] byte offsets of the source rows in the plane of maxima*/,
-    const uint32_t *__restrict__ rowchg, HarmParams prm, WorkItem *__restrict__ work, unsigned int *__restrict__ ctl,
-    unsigned int limit, int xcd_remap, const unsigned int *__restrict__ flags, uint32_t group0)
+// NG: groups per lane, 256 apart (a workgroup walks 256 * NG consecutive groups): the row's scalar work -- which
+// sources moved, their rows' offsets, the branches -- is shared by NG times the loads.
+// rowpf[zi][0 .. NHS]: the address of each source's row for fundamental row zi, in the plane of upper halves
+// (sources bounded from cells) or in the plane of maxima (from windows), and in the last place the mask of the
+// sources whose row moved since row zi - 1: everything a row's scalar side needs, in one run of memory.
+template <int NSTAGES, int NG, int NT = 256>
+__global__ __launch_bounds__(NT) void k_prefilter_lanes(
+    const unsigned short *__restrict__ mx, int numz, GroupGrid g, int64_t ngroups, const int64_t *__restrict__ rowpf,
+    HarmParams prm, WorkItem *__restrict__ work, unsigned int *__restrict__ ctl, unsigned int limit, int xcd_remap,
+    const unsigned int *__restrict__ flags, uint32_t group0)
 {
     constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
     __shared__ PfShared sh;
@@ -1647,7 +1723,7 @@ __global__ __launch_bounds__(256) void k_prefilter_lanes(
     if (xcd_remap) {
         const unsigned int per = (gridDim.x + 7) / 8; // 8 XCDs
         tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
-        if ((int64_t) tile * 256 >= ngroups)
+        if ((int64_t) tile * (NT * NG) >= ngroups)
             return;
     }
     if (flags[0] != 0) { // negative powers in the plane: the bounds do not hold
@@ -1657,254 +1733,151 @@ __global__ __launch_bounds__(256) void k_prefilter_lanes(
     }
     if (!pf_begin(sh, ctl))
         return; // given up before this workgroup started
-    // the lane's group among the `ngroups` walked, which begin with group0 of the search region (a context that
+    // the lane's groups among the `ngroups` walked, which begin with group0 of the search region (a context that
     // searches a range of blocks only)
-    const int64_t gid = (int64_t) tile * 256 + threadIdx.x;
-    const bool live = gid < ngroups;
-    const uint32_t gl = group0 + (live ? (uint32_t) gid : 0u);
-    // the group's columns within the search region
-    const uint32_t sb = gl / (uint32_t) kGpb;
-    const int lg = (int) (gl % (uint32_t) kGpb);
-    const int lfirst = max(4 * lg - g.a, 0), llast = min(4 * lg - g.a + 3, kUseLen - 1);
-    const uint32_t cf = (uint32_t) g.search_col0 + sb * (uint32_t) kUseLen + (uint32_t) lfirst, cl = cf + (uint32_t) (llast - lfirst);
-    const uint32_t foff = 2u * ((uint32_t) (g.nprepop + sb) * (uint32_t) kGpb + (uint32_t) lg); // the group's own entry in a row
-    uint32_t off[NHS]; // byte offset in a row of the first of a source's two entries; bit 0: the second is the next entry
-    bool force = false; // a source whose cells are not covered by two consecutive entries: always listed
-    {
+    bool live[NG], force[NG]; // force: a source that one entry (or two cells) does not bound: always listed
+    uint32_t gl[NG], foff[NG]; // the group's number in the search region; its own entry's byte offset in a row
+    uint32_t off[NG][NHS];     // see source_offset()
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+        const int64_t gid = (int64_t) tile * (NT * NG) + NT * k + threadIdx.x;
+        live[k] = gid < ngroups;
+        gl[k] = group0 + (live[k] ? (uint32_t) gid : 0u);
+        // the group's columns within the search region
+        const uint32_t sb = gl[k] / (uint32_t) kGpb;
+        const int lg = (int) (gl[k] % (uint32_t) kGpb);
+        const int lfirst = max(4 * lg - g.a, 0), llast = min(4 * lg - g.a + 3, kUseLen - 1);
+        const uint32_t cf = (uint32_t) g.search_col0 + sb * (uint32_t) kUseLen + (uint32_t) lfirst, cl = cf + (uint32_t) (llast - lfirst);
+        foff[k] = 2u * ((uint32_t) (g.nprepop + sb) * (uint32_t) kGpb + (uint32_t) lg);
+        force[k] = false;
         int i = 0;
 #pragma unroll
         for (int s = 1; s < NSTAGES; s++)
 #pragma unroll
             for (int h = 1; h < (1 << s); h += 2) {
-                const uint32_t s0 = (uint32_t) (((uint64_t) cf * h + (1u << (s - 1))) >> s), s1 = (uint32_t) (((uint64_t) cl * h + (1u << (s - 1))) >> s);
-                uint32_t e0 = 0, d = 3;
-                if (s0 >= (uint32_t) g.prepop_col0) {
-                    e0 = group_entry_of(g, s0);
-                    d = group_entry_of(g, s1) - e0;
-                }
-                if (d == 2) { // three entries: fine when the middle one is a block's short group (it stands for six columns)
-                    const uint32_t mid = (e0 + 1) % (uint32_t) kGpb;
-                    if (g.a == 0 && mid == (uint32_t) kGpb - 1) {
-                        e0 += 1;
-                        d = 1;
-                    } else if (g.a == 2 && mid == 0) {
-                        d = 1;
-                    }
-                }
-                if (d > 1) {
-                    force = true;
-                    e0 = 0;
-                    d = 0;
-                }
-                off[i++] = 2 * e0 + d;
+                force[k] = !source_offset(g, cf, cl, s, h, off[k][i]) || force[k];
+                i++;
                 __builtin_amdgcn_sched_barrier(0); // one source after the other: interleaved, the set-up sets the register count
             }
     }
+    unsigned long long live_mask[NG], force_mask[NG];
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+        live_mask[k] = __ballot(live[k]);
+        force_mask[k] = __ballot(force[k]);
+    }
     const char *mbytes = reinterpret_cast<const char *>(mx);
     const int64_t rowb = 2 * g.mxlen;
-    uint32_t v0[NHS], v1[NHS];
+    // Values are loaded into the UPPER half of their registers (the lower half is and stays zero): an entry of the
+    // plane of maxima is then the float bound as it stands, a cell's upper half the float it is the upper half of.
+    // The compiler has no such load for these parts (it assumes a 16-bit load may not leave the other half alone),
+    // so the loads are written out, and so is the one wait per row -- the compiler does not count them.
+    uint32_t fm[NG], v[NG][NHS], v2[NG][NHS]; // (v2: the second cell of the sources bounded from cells; unused otherwise)
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+        fm[k] = 0;
+        asm volatile("" : "+v"(fm[k]));
+        int i = 0;
+#pragma unroll
+        for (int s = 1; s < NSTAGES; s++)
+#pragma unroll
+            for (int h = 1; h < (1 << s); h += 2) {
+                v[k][i] = 0;
+                asm volatile("" : "+v"(v[k][i]));
+                if (pf_from_cells(s, h)) {
+                    v2[k][i] = 0;
+                    asm volatile("" : "+v"(v2[k][i]));
+                }
+                i++;
+            }
+    }
+#define PF_LOAD_HI(dst, voff, sbase) asm volatile("global_load_short_d16_hi %0, %1, %2" : "+v"(dst) : "v"(voff), "s"(sbase))
     // (the first row loads every source -- what rowchg[0] says anyway: spelt out, the compiler knows that no source
-    // value enters the loop undefined, and the kernel needs 62 registers instead of 73: eight waves per SIMD)
+    // value enters the loop undefined, and the kernel needs fewer registers)
     int zfirst = 0;
     asm volatile("" : "+s"(zfirst));
     for (int zi = zfirst; zi < numz; zi++) {
-        const uint32_t fm = *reinterpret_cast<const unsigned short *>(mbytes + (size_t) zi * (size_t) rowb + foff);
-        const uint32_t chg = NH == 0 ? 0u : zi == zfirst ? ~0u : rowchg[zi];
+        const char *own = mbytes + (size_t) zi * (size_t) rowb;
+#pragma unroll
+        for (int k = 0; k < NG; k++)
+            PF_LOAD_HI(fm[k], foff[k], own);
+        const int64_t *rp = rowpf + (size_t) zi * (NHS + 1);
         int64_t ro[NHS];
 #pragma unroll
         for (int i = 0; i < NH; i++)
-            ro[i] = rowmx[(size_t) zi * NHS + i];
+            ro[i] = rp[i];
+        const uint32_t chg = NH == 0 ? 0u : zi == zfirst ? ~0u : (uint32_t) rp[NHS];
 #pragma unroll
-        for (int i = 0; i < NH; i++)
-            asm volatile("" : "+v"(off[i]));
+        for (int k = 0; k < NG; k++)
 #pragma unroll
-        for (int i = 0; i < NH; i++) {
-            if (chg & (1u << i)) {
-                const char *src = mbytes + ro[i];
-                const uint32_t o0 = off[i] & ~1u, o1 = o0 + ((off[i] & 1u) << 1);
-                v0[i] = *reinterpret_cast<const unsigned short *>(src + o0);
-                v1[i] = *reinterpret_cast<const unsigned short *>(src + o1);
-            }
-        }
-        float p = bound_value(fm);
-        bool any = force;
+            for (int i = 0; i < NH; i++)
+                asm volatile("" : "+v"(off[k][i]));
         {
             int i = 0;
 #pragma unroll
-            for (int s = 0; s < NSTAGES; s++) {
-                if (s > 0) {
+            for (int s = 1; s < NSTAGES; s++)
 #pragma unroll
-                    for (int h = 1; h < (1 << s); h += 2) {
-                        p += bound_value(max(v0[i], v1[i]));
-                        i++;
+                for (int h = 1; h < (1 << s); h += 2) {
+                    if (chg & (1u << i)) {
+                        if (pf_from_cells(s, h)) {
+                            const char *src = reinterpret_cast<const char *>(ro[i]);
+#pragma unroll
+                            for (int k = 0; k < NG; k++) {
+                                const uint32_t o0 = off[k][i] & ~1u, o1 = o0 + ((off[k][i] & 1u) << 1);
+                                PF_LOAD_HI(v[k][i], o0, src);
+                                PF_LOAD_HI(v2[k][i], o1, src);
+                            }
+                        } else {
+                            const char *src = reinterpret_cast<const char *>(ro[i]);
+#pragma unroll
+                            for (int k = 0; k < NG; k++)
+                                PF_LOAD_HI(v[k][i], off[k][i], src);
+                        }
                     }
+                    i++;
                 }
-                any |= !(p <= prm.powcut[s]); // a NaN (the bound of an infinite power) counts as a crossing
-            }
         }
-        any = any && live;
-        const unsigned long long mask = __ballot(any);
-        if (mask)
-            pf_insert(sh, mask, any, lane, WorkItem{(uint32_t) zi, gl}, work, ctl, limit);
-    }
-    __syncthreads();
-    pf_flush(sh, work, ctl, limit);
-}
-
-// The entries of one source that bound the cells of one group of four fundamental columns (first column cf,
-// last cl): e0 and, if d == 1, the next one.  d > 1: two consecutive entries do not cover them (a source
-// below the plane, or cells spread over three entries).
-__device__ __forceinline__ void source_entries(const GroupGrid &g, uint32_t cf, uint32_t cl, int s, int h, uint32_t &e0, uint32_t &d)
-{
-    const uint32_t s0 = (uint32_t) (((uint64_t) cf * h + (1u << (s - 1))) >> s), s1 = (uint32_t) (((uint64_t) cl * h + (1u << (s - 1))) >> s);
-    e0 = 0;
-    d = 3;
-    if (s0 >= (uint32_t) g.prepop_col0) {
-        e0 = group_entry_of(g, s0);
-        d = group_entry_of(g, s1) - e0;
-    }
-    if (d == 2) { // three entries: fine when the middle one is a block's short group (it stands for six columns)
-        const uint32_t mid = (e0 + 1) % (uint32_t) kGpb;
-        if (g.a == 0 && mid == (uint32_t) kGpb - 1) {
-            e0 += 1;
-            d = 1;
-        } else if (g.a == 2 && mid == 0) {
-            d = 1;
-        }
-    }
-}
-// v_perm_b32 selector that puts entry j0 of four consecutive ones (8 bytes) in the lower half and entry j1 in the upper
-__device__ __forceinline__ uint32_t pair_selector(uint32_t j0, uint32_t j1)
-{
-    return (2u * j0) | ((2u * j0 + 1u) << 8) | ((2u * j1) << 16) | ((2u * j1 + 1u) << 24);
-}
-
-// k_prefilter_lanes is bound by the number of its load instructions (two 16-bit loads per source, lane and
-// move of the source's row), not by bytes.  Here a group's two entries of a source come out of ONE 8-byte load
-// at a 4-byte boundary: four consecutive entries from an even one; a byte permute picks the two.  NG = 2: a
-// lane takes two ADJACENT groups (eight columns): their own entries are one aligned 32-bit word, and the
-// entries both need of a source lie within the same four -- a quarter of the load instructions per group.
-template <int NSTAGES, int NG>
-__global__ __launch_bounds__(256) void k_prefilter_pairs(
-    const unsigned short *__restrict__ mx, int numz, GroupGrid g, int64_t ngroups,
-    const int64_t *__restrict__ rowmx /*[numz][NHS] byte offsets of the source rows in the plane of maxima*/,
-    const uint32_t *__restrict__ rowchg, HarmParams prm, WorkItem *__restrict__ work, unsigned int *__restrict__ ctl,
-    unsigned int limit, int xcd_remap, const unsigned int *__restrict__ flags, uint32_t group0)
-{
-    constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
-    __shared__ PfShared sh;
-    const int lane = threadIdx.x & 63;
-    const int64_t npairs = ngroups / NG; // lanes wanted (groups per block and hence in all: even)
-    unsigned int tile = blockIdx.x;
-    if (xcd_remap) {
-        const unsigned int per = (gridDim.x + 7) / 8; // 8 XCDs
-        tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
-        if ((int64_t) tile * 256 >= npairs)
-            return;
-    }
-    if (flags[0] != 0) { // negative powers in the plane: the bounds do not hold
-        if (blockIdx.x == 0 && threadIdx.x == 0)
-            pf_give_up(ctl);
-        return;
-    }
-    if (!pf_begin(sh, ctl))
-        return; // given up before this workgroup started
-    const int64_t pid = (int64_t) tile * 256 + threadIdx.x;
-    const bool live = pid < npairs;
-    const uint32_t gidA = group0 + (live ? (uint32_t) NG * (uint32_t) pid : 0u); // the first of the lane's groups (group0: even)
-    const uint32_t sb = gidA / (uint32_t) kGpb;
-    const int lgA = (int) (gidA % (uint32_t) kGpb);
-    uint32_t cf[NG], cl[NG];
+        asm volatile("s_waitcnt vmcnt(0)");
 #pragma unroll
-    for (int k = 0; k < NG; k++) {
-        const int lg = lgA + k;
-        const int lfirst = max(4 * lg - g.a, 0), llast = min(4 * lg - g.a + 3, kUseLen - 1);
-        cf[k] = (uint32_t) g.search_col0 + sb * (uint32_t) kUseLen + (uint32_t) lfirst;
-        cl[k] = cf[k] + (uint32_t) (llast - lfirst);
-    }
-    const uint32_t foff = 2u * ((uint32_t) (g.nprepop + sb) * (uint32_t) kGpb + (uint32_t) lgA); // the groups' own entries (two: a multiple of 4)
-    uint32_t off[NHS];    // byte offset in a row of the first of the four entries loaded of source i (a multiple of 4)
-    uint32_t sel[NG][NHS]; // per group: the byte permute that picks its two entries out of the four
-    bool force[NG] = {}; // a group whose source cells the four entries do not cover: always listed
-    {
-        int i = 0;
+        for (int k = 0; k < NG; k++) { // (ties every loaded register to the wait: the sums below come after it)
+            asm volatile("" : "+v"(fm[k]));
+            int i = 0;
 #pragma unroll
-        for (int s = 1; s < NSTAGES; s++)
+            for (int s = 1; s < NSTAGES; s++)
 #pragma unroll
-            for (int h = 1; h < (1 << s); h += 2) {
-                uint32_t e0[NG], d[NG];
-#pragma unroll
-                for (int k = 0; k < NG; k++)
-                    source_entries(g, cf[k], cl[k], s, h, e0[k], d[k]);
-                const uint32_t eb = (d[0] <= 1 ? e0[0] : d[NG - 1] <= 1 ? e0[NG - 1] : 0u) & ~1u;
-#pragma unroll
-                for (int k = 0; k < NG; k++) {
-                    const uint32_t j0 = e0[k] - eb; // wraps round to a large number below eb
-                    const bool ok = d[k] <= 1 && j0 + d[k] <= 3u;
-                    force[k] = force[k] || !ok;
-                    sel[k][i] = ok ? pair_selector(j0, j0 + d[k]) : 0x03020100u;
+                for (int h = 1; h < (1 << s); h += 2) {
+                    asm volatile("" : "+v"(v[k][i]));
+                    if (pf_from_cells(s, h))
+                        asm volatile("" : "+v"(v2[k][i]));
+                    i++;
                 }
-                off[i++] = 2u * eb;
-                __builtin_amdgcn_sched_barrier(0); // one source after the other: interleaved, the set-up sets the register count
-            }
-    }
-    const unsigned long long live_mask = __ballot(live);
-    unsigned long long force_mask[NG];
-#pragma unroll
-    for (int k = 0; k < NG; k++)
-        force_mask[k] = __ballot(force[k]);
-    const char *mbytes = reinterpret_cast<const char *>(mx);
-    const int64_t rowb = 2 * g.mxlen;
-    uint2 w[NHS];
-    for (int zi = 0; zi < numz; zi++) {
-        const char *own = mbytes + (size_t) zi * (size_t) rowb + foff;
-        const uint32_t fm = NG == 2 ? *reinterpret_cast<const uint32_t *>(own) : (uint32_t) *reinterpret_cast<const unsigned short *>(own);
-        const uint32_t chg = NH > 0 ? rowchg[zi] : 0u;
-        int64_t ro[NHS];
-#pragma unroll
-        for (int i = 0; i < NH; i++)
-            ro[i] = rowmx[(size_t) zi * NHS + i];
-#pragma unroll
-        for (int i = 0; i < NH; i++)
-            asm volatile("" : "+v"(off[i]));
-#pragma unroll
-        for (int i = 0; i < NH; i++) {
-            if (chg & (1u << i))
-                __builtin_memcpy(&w[i], __builtin_assume_aligned(mbytes + ro[i] + off[i], 4), 8); // one 8-byte load at a 4-byte boundary
         }
-        unsigned long long crossing[NG];
 #pragma unroll
         for (int k = 0; k < NG; k++) {
-            // bound_value() of the group's own entry: the word's lower / upper half
-            float p = __uint_as_float(k == 0 ? (fm << 16) + 0x10000u : (fm & 0xffff0000u) + 0x10000u);
-            crossing[k] = force_mask[k];
+            float p = __uint_as_float(fm[k]);
+            // (one compare per stage, each straight into a lane mask: as a bool per lane, or-ed up, the compiler spends a
+            // dozen vector instructions on the five bits)
+            unsigned long long mask = force_mask[k];
             int i = 0;
 #pragma unroll
             for (int s = 0; s < NSTAGES; s++) {
                 if (s > 0) {
 #pragma unroll
                     for (int h = 1; h < (1 << s); h += 2) {
-                        const uint32_t two = __builtin_amdgcn_perm(w[i].y, w[i].x, sel[k][i]);
-                        uint32_t m;
-                        asm("v_pk_max_u16 %0, %1, %1 op_sel:[1,0]" : "=v"(m) : "v"(two)); // lower half: the larger of the two entries
-                        p += __uint_as_float((m << 16) + 0x10000u);                       // the upper half's leftovers shift out
+                        p += __uint_as_float(pf_from_cells(s, h) ? max(v[k][i], v2[k][i]) + 0x10000u : v[k][i]);
                         i++;
                     }
                 }
-                crossing[k] |= __ballot(!(p <= prm.powcut[s])); // a NaN (the bound of an infinite power) counts as a crossing
+                mask |= __ballot(!(p <= prm.powcut[s])); // a NaN (the bound of an infinite power) counts as a crossing
             }
-            crossing[k] &= live_mask;
-        }
-#pragma unroll
-        for (int k = 0; k < NG; k++) {
-            const unsigned long long mask = crossing[k];
+            mask &= live_mask[k];
             if (mask)
-                pf_insert(sh, mask, (mask >> lane) & 1ull, lane, WorkItem{(uint32_t) zi, gidA + (uint32_t) k},
-                          work, ctl, limit);
+                pf_insert(sh, mask, (mask >> lane) & 1ull, lane, WorkItem{(uint32_t) zi, gl[k]}, work, ctl, limit);
         }
     }
+#undef PF_LOAD_HI
     __syncthreads();
-    pf_flush(sh, work, ctl, limit);
+    pf_flush<NT>(sh, work, ctl, limit);
 }
 
 // How long would the list be?  Asked before the walk (see the note on the control words): every lane takes one
@@ -1915,9 +1888,9 @@ __global__ __launch_bounds__(256) void k_prefilter_pairs(
 // the samples listed, and the flag goes up.
 template <int NSTAGES>
 __global__ __launch_bounds__(256) void k_prefilter_sample(
-    const unsigned short *__restrict__ mx, int numz, GroupGrid g, int64_t ngroups, const int64_t *__restrict__ rowmx,
-    HarmParams prm, unsigned int *__restrict__ ctl, unsigned int nsamples, unsigned int gstep, unsigned int sample_limit,
-    const unsigned int *__restrict__ flags, uint32_t group0)
+    const unsigned short *__restrict__ mx, const unsigned short *__restrict__ hi, int numz, GroupGrid g, int64_t ngroups,
+    const int64_t *__restrict__ rowpf, HarmParams prm, unsigned int *__restrict__ ctl, unsigned int nsamples, unsigned int gstep,
+    unsigned int sample_limit, const unsigned int *__restrict__ flags, uint32_t group0)
 {
     constexpr int NHS = HarmShape<NSTAGES>::NHS;
     __shared__ unsigned int found;
@@ -1941,7 +1914,7 @@ __global__ __launch_bounds__(256) void k_prefilter_sample(
     const size_t rowb = 2 * (size_t) g.mxlen;
     const uint32_t fm = *reinterpret_cast<const unsigned short *>(mbytes + (size_t) zi * rowb +
                                                                   2 * ((size_t) (g.nprepop + sb) * kGpb + (size_t) lg));
-    float p = bound_value(fm);
+    float p = __uint_as_float(fm << 16); // (an entry is the bound's upper half: bound_entry)
     bool any = !(p <= prm.powcut[0]);
     {
         int i = 0;
@@ -1949,17 +1922,17 @@ __global__ __launch_bounds__(256) void k_prefilter_sample(
         for (int s = 1; s < NSTAGES; s++) {
 #pragma unroll
             for (int h = 1; h < (1 << s); h += 2) {
-                uint32_t e0, d;
-                source_entries(g, cf, cl, s, h, e0, d);
-                if (d > 1) { // not covered by two consecutive entries: always listed
-                    any = true;
-                    e0 = 0;
-                    d = 0;
+                uint32_t off;
+                any = !source_offset(g, cf, cl, s, h, off) || any; // not bounded by one entry or two cells: always listed
+                const char *src = reinterpret_cast<const char *>(rowpf[(size_t) zi * (NHS + 1) + i]);
+                if (pf_from_cells(s, h)) {
+                    const uint32_t o0 = off & ~1u, o1 = o0 + ((off & 1u) << 1);
+                    const uint32_t a = *reinterpret_cast<const unsigned short *>(src + o0);
+                    const uint32_t b = *reinterpret_cast<const unsigned short *>(src + o1);
+                    p += bound_value(max(a, b));
+                } else {
+                    p += __uint_as_float((uint32_t) *reinterpret_cast<const unsigned short *>(src + off) << 16);
                 }
-                const char *src = mbytes + rowmx[(size_t) zi * NHS + i];
-                const uint32_t a = *reinterpret_cast<const unsigned short *>(src + 2 * (size_t) e0);
-                const uint32_t b = *reinterpret_cast<const unsigned short *>(src + 2 * (size_t) (e0 + d));
-                p += bound_value(max(a, b));
                 i++;
             }
             any |= !(p <= prm.powcut[s]); // a NaN (the bound of an infinite power) counts as a crossing

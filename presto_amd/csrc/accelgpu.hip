@@ -115,7 +115,8 @@ struct Tuning {
                             // walk is given up and the bounded sum runs over the whole plane
     int pf_sample = 1;      // ask a sample of the (row, group)s how long the list would be before walking them all
     int pf_memory = 1;      // a context whose coarse bound was given up leaves it out of its next trials (4, 8, ... 64 of them)
-    int pf_pairs = 1;       // coarse bound from 8-byte loads: 1 two adjacent groups per lane up to 8 harmonics, 2: with 16 too,
+    int pf_nt = 0;          // threads per workgroup of that kernel: 0 by the number of groups, 256 / 512 / 1024 that many
+    int pf_groups = 0;      // groups of four columns per lane in the coarse bound's kernel: 0 two up to 8 harmonics, one with 16; 1 / 2: always,
                             // 3: one group per lane, 0: never
                             // (0: off, float plane only; 1: on; 2 / 3: on, one / two columns per lane forced)
 };
@@ -618,7 +619,7 @@ int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const i
     if (rr && zl && ctx->fftlen == 8192 && pair && d_hi && d_mx) {
         // with the largest upper half of every four outputs, for the coarse bound in front of the harmonic sum
         hipLaunchKernelGGL((accelk::k_correlate_rr<P8K, false, 16, true, afft::NoStamp, true, true, true>), rgrid, dim3(P8K::NT),
-                           P8K::LDS_BYTES + std::min(std::max(tn.corr_lds, 0), 20000), ctx->stream, ctx->d_bank, d_blockfft, d_col,
+                           P8K::LDS_BYTES + accelk::kMaximaLdsBytes, ctx->stream, ctx->d_bank, d_blockfft, d_col,
                            d_ncols, nblk, chunk, d_plane, rlen, ctx->halfwidth, ctx->pw_inv.pw1, ctx->pw_inv.pw2, ctx->numz,
                            tile_z, tile_c, afft::NoStamp(), d_hi, d_lo, d_mx, mxlen, d_zrange);
     } else if (rr && zl && ctx->fftlen == 8192 && pair) {
@@ -743,8 +744,24 @@ int ensure_prefilter(accelgpu_ctx *ctx)
     if (nh > 0) {
         std::vector<int64_t> half((size_t) nh * ctx->numz), tab(half.size());
         HIPCHK(hipMemcpy(half.data(), ctx->d_rowhalf, half.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
-        for (size_t k = 0; k < half.size(); k++)
-            tab[k] = half[k] / (2 * su.rlen) * (2 * g.mxlen);
+        // a source's row in the plane it is bounded from, as an address (the walk spends no scalar additions on it): the
+        // plane of upper halves for harmonics up to 1/4, the plane of maxima for the others (accelk::pf_from_cells).
+        // Both planes stay where they are until the search is set again, which builds this table again.
+        std::vector<char> cells;
+        for (int s = 1; s < su.numharmstages; s++)
+            for (int h = 1; h < (1 << s); h += 2)
+                cells.push_back(accelk::pf_from_cells(s, h));
+        std::vector<uint32_t> chg((size_t) ctx->numz);
+        HIPCHK(hipMemcpy(chg.data(), ctx->d_rowchg, chg.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        tab.assign((size_t) (nh + 1) * ctx->numz, 0);
+        for (int zi = 0; zi < ctx->numz; zi++) {
+            for (int i = 0; i < nh; i++) {
+                const int64_t hb = half[(size_t) zi * nh + i];
+                tab[(size_t) zi * (nh + 1) + i] = cells[(size_t) i] ? (int64_t) (uintptr_t) ctx->d_hi + hb
+                                                                  : (int64_t) (uintptr_t) ctx->d_mx + hb / (2 * su.rlen) * (2 * g.mxlen);
+            }
+            tab[(size_t) zi * (nh + 1) + nh] = (int64_t) chg[(size_t) zi]; // which sources' rows moved since the row before
+        }
         if ((rc = dev_reserve(&ctx->d_rowmx, &ctx->rowmx_cap, tab.size(), false, ctx->stream))) return rc;
         HIPCHK(hipMemcpy(ctx->d_rowmx, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     }
@@ -816,14 +833,16 @@ int launch_prefilter(accelgpu_ctx *ctx, int nstages, const accelk::HarmParams &p
     }
     const int64_t ngroups = (int64_t) ctx->range_count * accelk::kGpb; // of the blocks this context searches
     const uint32_t group0 = (uint32_t) ctx->range_first * (uint32_t) accelk::kGpb;
-    // One 8-byte load per source (k_prefilter_pairs): with up to 8 harmonics a lane takes two adjacent groups (a
-    // quarter of the load instructions: 0.69 against 0.95 ms on a 2^23-point, zmax 200 plane).  With 16 harmonics
-    // its registers leave five waves per SIMD: 1.71 ms with two groups per lane, 2.28 with one, against 1.72 ms
-    // for two 16-bit loads per source (k_prefilter_lanes), which lists fewer groups and stays.  pf_pairs: 0 never,
-    // 2 two groups per lane with 16 harmonics too, 3 one group per lane.
-    const int pp = ctx->tune.pf_pairs;
-    const int per_lane = nstages > 5 || pp == 0 ? 0 : pp == 3 ? 1 : pp == 2 ? 2 : nstages <= 4 ? 2 : 0;
-    unsigned nt = (unsigned) ((ngroups / std::max(per_lane, 1) + 255) / 256);
+    // Groups per lane: with up to 8 harmonics a lane takes two groups 256 apart (the row's scalar work is shared by
+    // twice the loads), with 16 one (two cost it its eight waves per SIMD).  pf_groups: 0 as said, 1 / 2 always that many.
+    const int pp = ctx->tune.pf_groups;
+    const int per_lane = pp == 1 || pp == 2 ? pp : nstages <= 4 ? 2 : 1;
+    // Threads per workgroup: 1024 where that still makes several workgroups per CU (the waves of a workgroup walk
+    // neighbouring columns and share the lines of the low harmonics' sources: 1.24 against 1.39 ms with 256 on a
+    // 2^23-point, zmax 200 plane); pf_nt = 256 / 512 / 1024 forces one.
+    const int pn = ctx->tune.pf_nt;
+    const int wg = pn == 256 || pn == 512 || pn == 1024 ? pn : ngroups >= (int64_t) 1024 * per_lane * 1024 ? 1024 : ngroups >= (int64_t) 512 * per_lane * 1024 ? 512 : 256;
+    unsigned nt = (unsigned) ((ngroups + wg * per_lane - 1) / (wg * per_lane));
     if (remap)
         nt = ((nt + 7) / 8) * 8;
     unsigned int wcap = (unsigned int) std::min<size_t>(ctx->work_cap, 0xFFFFFFFFu);
@@ -839,20 +858,25 @@ int launch_prefilter(accelgpu_ctx *ctx, int nstages, const accelk::HarmParams &p
     const unsigned int nsamples = (unsigned int) std::min<double>(32768.0, all_entries);
     unsigned int gstep = (unsigned int) ((double) ngroups * 0.6180339887) | 1u;
     const unsigned int sample_limit = (unsigned int) std::min<double>(4294967295.0, std::ceil((double) wcap * (double) nsamples / all_entries));
+#define LAUNCH_WALK_AS(NS, NG, NT)                                                                             \
+    hipLaunchKernelGGL((accelk::k_prefilter_lanes<NS, NG, NT>), dim3(nt), dim3(NT), 0, ctx->stream, ctx->d_mx, ctx->numz, g,  \
+                       ngroups, ctx->d_rowmx, prm, ctx->d_work, ctx->d_ctl, wcap, remap, ctx->d_flags, group0)
+#define LAUNCH_WALK(NS)                                                                                        \
+    do {                                                                                                       \
+        if (per_lane == 2 && wg == 1024) LAUNCH_WALK_AS(NS, 2, 1024);                                          \
+        else if (per_lane == 2 && wg == 512) LAUNCH_WALK_AS(NS, 2, 512);                                       \
+        else if (per_lane == 2) LAUNCH_WALK_AS(NS, 2, 256);                                                    \
+        else if (wg == 1024) LAUNCH_WALK_AS(NS, 1, 1024);                                                      \
+        else if (wg == 512) LAUNCH_WALK_AS(NS, 1, 512);                                                        \
+        else LAUNCH_WALK_AS(NS, 1, 256);                                                                       \
+    } while (0)
 #define LAUNCH_PF(NS)                                                                                          \
     do {                                                                                                       \
         if (ctx->tune.pf_sample)                                                                               \
             hipLaunchKernelGGL((accelk::k_prefilter_sample<NS>), dim3((nsamples + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_mx, \
-                               ctx->numz, g, ngroups, ctx->d_rowmx, prm, ctx->d_ctl, nsamples, gstep, sample_limit, ctx->d_flags, group0); \
-        if (per_lane == 2)                                                                                     \
-            hipLaunchKernelGGL((accelk::k_prefilter_pairs<(NS > 5 ? 5 : NS), 2>), dim3(nt), dim3(256), 0, ctx->stream, ctx->d_mx, ctx->numz, g, \
-                               ngroups, ctx->d_rowmx, ctx->d_rowchg, prm, ctx->d_work, ctx->d_ctl, wcap, remap, ctx->d_flags, group0); \
-        else if (per_lane == 1)                                                                                \
-            hipLaunchKernelGGL((accelk::k_prefilter_pairs<(NS > 5 ? 5 : NS), 1>), dim3(nt), dim3(256), 0, ctx->stream, ctx->d_mx, ctx->numz, g, \
-                               ngroups, ctx->d_rowmx, ctx->d_rowchg, prm, ctx->d_work, ctx->d_ctl, wcap, remap, ctx->d_flags, group0); \
-        else                                                                                                   \
-            hipLaunchKernelGGL((accelk::k_prefilter_lanes<NS>), dim3(nt), dim3(256), 0, ctx->stream, ctx->d_mx, ctx->numz, g, \
-                               ngroups, ctx->d_rowmx, ctx->d_rowchg, prm, ctx->d_work, ctx->d_ctl, wcap, remap, ctx->d_flags, group0); \
+                               ctx->d_hi, ctx->numz, g, ngroups, ctx->d_rowmx, prm, ctx->d_ctl, nsamples, gstep, sample_limit,     \
+                               ctx->d_flags, group0);                                                          \
+        LAUNCH_WALK(NS);                                                                                       \
         hipLaunchKernelGGL((accelk::k_flagged_exact<NS>), dim3(4096), dim3(256), 0, ctx->stream, ctx->d_hi, ctx->d_lo,       \
                            ctx->setup.rlen, g, ctx->d_rowhalf, prm, ctx->d_work, ctx->d_ctl, wcap, out.hits, out.count, cap); \
     } while (0)
@@ -864,6 +888,8 @@ int launch_prefilter(accelgpu_ctx *ctx, int nstages, const accelk::HarmParams &p
     default: LAUNCH_PF(6); break;
     }
 #undef LAUNCH_PF
+#undef LAUNCH_WALK
+#undef LAUNCH_WALK_AS
     HIPCHK(hipGetLastError());
     return ACCELGPU_OK;
 }
@@ -1366,7 +1392,7 @@ const TuneName kTuneNames[] = {
     {"std_table", &Tuning::std_table},       {"std_blocks", &Tuning::std_blocks},
     {"opt_nt", &Tuning::opt_nt},             {"use_graph", &Tuning::use_graph},
     {"hs_bound", &Tuning::hs_bound},         {"pf_list_cap", &Tuning::pf_list_cap},
-    {"pf_pairs", &Tuning::pf_pairs},         {"pf_limit_ppm", &Tuning::pf_limit_ppm},
+    {"pf_groups", &Tuning::pf_groups},       {"pf_nt", &Tuning::pf_nt},         {"pf_limit_ppm", &Tuning::pf_limit_ppm},
     {"pf_memory", &Tuning::pf_memory},       {"pf_sample", &Tuning::pf_sample},
 };
 
@@ -1523,6 +1549,7 @@ int accelgpu_create(accelgpu_ctx **out, int device)
     if ((rc = allow_lds(accelk::k_correlate_rr<P8K, false, 16, true, afft::NoStamp, true>, P8K::LDS_BYTES + 20000))) return rc;
     if ((rc = allow_lds(accelk::k_correlate_rr<P8K, false, 16, true, afft::NoStamp, true, true>, P8K::LDS_BYTES + 20000))) return rc;
     if ((rc = allow_lds(accelk::k_correlate_rr<P8K, false, 16, true, afft::NoStamp, false, true>, P8K::LDS_BYTES + 20000))) return rc;
+    if ((rc = allow_lds(accelk::k_correlate_rr<P8K, false, 16, true, afft::NoStamp, true, true, true>, P8K::LDS_BYTES + 20000))) return rc;
     if ((rc = allow_lds(accelk::k_correlate_rr<P16K, false, 16, true, afft::NoStamp, true>, P16K::LDS_BYTES + 20000))) return rc;
     if ((rc = allow_lds(accelk::k_fft_rows<P8K, -1>, P8K::LDS_BYTES))) return rc;
     if ((rc = allow_lds(accelk::k_fft_rows<P16K, -1>, P16K::LDS_BYTES))) return rc;

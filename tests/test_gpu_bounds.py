@@ -65,9 +65,8 @@ def test_same_hits_for_every_number_of_harmonics(gpu, numharm, zmax):
 @pytest.mark.parametrize("numharm", [2, 4, 8, 16])
 @pytest.mark.parametrize("zmax", [0, 50])
 def test_coarse_bound_one_or_two_groups_per_lane(gpu, numharm, zmax):
-    """The coarse bound's two kernels (a lane sums one group of four columns with two 16-bit loads per source,
-    or two adjacent groups with one 8-byte load; pf_pairs picks) list different (row, group)s where a source's
-    entries fall outside the loaded ones, and must end in the same hits as the float-plane sum."""
+    """The coarse bound's kernel with one group of four columns per lane and with two (pf_groups picks; left
+    alone, two up to 8 harmonics and one with 16) must end in the same hits as the float-plane sum."""
     N, dt = 1 << 20, 1e-4
     fft = synth.make_fft(N, dt, [dict(f=223.456, z=5.0, amp=0.3, duty=0.08), dict(f=1741.0, z=-19.0, amp=0.2, duty=0.05)],
                          seed=400 + numharm)
@@ -75,15 +74,15 @@ def test_coarse_bound_one_or_two_groups_per_lane(gpu, numharm, zmax):
     gpu.load_fft(fft)
     try:
         res = _hits_by_mode(gpu, modes=(0,))
-        for pairs in (0, 1, 2, 3):
-            gpu.set_tuning("pf_pairs", pairs)
-            res[10 + pairs] = _hits_by_mode(gpu, modes=(4,))[4]
+        for groups in (0, 1, 2):
+            gpu.set_tuning("pf_groups", groups)
+            res[10 + groups] = _hits_by_mode(gpu, modes=(4,))[4]
             assert gpu.get_tuning("hs_prefilter_active") == 1 and gpu.get_tuning("pf_listed") > 0
     finally:
-        gpu.set_tuning("pf_pairs", 1)
+        gpu.set_tuning("pf_groups", 0)
     assert len(res[0]) > 50
     for m, h in res.items():
-        assert h.tobytes() == res[0].tobytes(), "pf_pairs=%d differs from the float-plane sum" % (m - 10)
+        assert h.tobytes() == res[0].tobytes(), "pf_groups=%d differs from the float-plane sum" % (m - 10)
 
 
 @pytest.mark.parametrize("numharm", [8, 32])

@@ -157,9 +157,9 @@ def test_cfg2_full_size_against_oracle(gpu, oracle):
 
 def test_cfg2_full_size_eight_harmonics_against_oracle(gpu, oracle):
     """The headline plane searched with accelsearch's default of 8 harmonics: the coarse bound then runs
-    its two-groups-per-lane kernel (k_prefilter_pairs), which planes of this size alone select."""
+    with two groups per lane, which planes of this size alone select."""
     matched, only_g, only_w = _oracle_parity(gpu, oracle, "cfg2", 1 << 23, 8_000_000, numharm=8, min_hits=100)
-    assert gpu.get_tuning("hs_prefilter_active") == 1 and gpu.get_tuning("pf_pairs") == 1
+    assert gpu.get_tuning("hs_prefilter_active") == 1 and gpu.get_tuning("pf_groups") == 0
     print("cfg2 2^23, 8 harmonics: %d hits matched, %d GPU-only, %d oracle-only at a threshold" % (matched, only_g, only_w))
 
 
