@@ -244,7 +244,7 @@ def main():
         g.set_profiling(True)
 
     # The same spectra with every threshold lowered to 0.85 of its value (reported beside): the coarse bound in
-    # front of the harmonic sum would then list 2 % of its (row, four columns) instead of 0.08 %, which costs more
+    # front of the harmonic sum would then list 2.7 % of its (row, four columns) instead of 0.1 %, which costs more
     # than it saves; a sample taken before the walk says so, the bounded sum runs over the whole plane instead,
     # and the context leaves the coarse bound out of its next trials.  (-sigma goes down to 1, spectra carry
     # interference: the rate must not fall off a cliff there.)
@@ -273,7 +273,7 @@ def main():
         # The harmonic sum as the reference defines it touches one value per (cell, source): the
         # fundamental and the sub-harmonics' Σ f^2 distinct cells per fundamental cell, 4 B each on a
         # float plane.  The kernels here read the plane's 16-bit upper halves (2 B per value), and with
-        # the coarse bound in front (the largest upper half of every four columns) a quarter of those;
+        # the coarse bound in front (one 16-bit bound per four columns) a quarter of those;
         # both halves only where a bound crosses a threshold.
         float_bytes = 4.0 * (1.0 + SUMF2[cfg["numharm"]]) * cells
         hs_alg = float_bytes / 8 if prefilter else float_bytes / 2 if bounded else float_bytes
@@ -297,7 +297,7 @@ def main():
             if pmc.get("prefilter", False) != prefilter or pmc.get("bounded", False) != bounded:
                 pmc = {}
         src = "profiles/pmc_kernels.json (rocprofv3 --pmc passes of this command, not this run)" if pmc else None
-        hs_name = ("k_prefilter_lanes / _pairs + k_flagged_exact <%d stages> over the maxima of four columns' upper halves" if prefilter
+        hs_name = ("k_prefilter_lanes + k_flagged_exact <%d stages> over one 16-bit bound per four columns (windows of eight)" if prefilter
                    else "k_harmsum_bw<%d stages> over 16-bit upper halves of the plane" if bounded
                    else "k_harmsum<%d stages>") % setup.numharmstages
         roof_hs = {"kernel": hs_name, "bound": "hbm", "achieved": hs_alg / (hs_ms * 1e-3) / 1e9 if hs_ms > 0 else 0.0,

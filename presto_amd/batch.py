@@ -33,9 +33,9 @@ def split_blocks(nblocks, world):
 
 
 # What a (block, z row) costs a rank: generating it (one inverse transform) against summing and thresholding its
-# cells, as measured on one MI355X for a 2^27-point, zmax 300, 16-harmonic search (69.3 ms of plane generation over
-# 17 968 x 301 rows, 32.6 ms of harmonic sum over 17 965 x 301).
-GEN_COST, SUM_COST = 69.3 / (17968 * 301), 32.6 / (17965 * 301)
+# cells, as measured on one MI355X for a 2^27-point, zmax 300, 16-harmonic search (70.4 ms of plane generation over
+# 17 968 x 301 rows, 24.2 ms of harmonic sum over 17 965 x 301).
+GEN_COST, SUM_COST = 70.4 / (17968 * 301), 24.2 / (17965 * 301)
 
 
 def range_cost(setup, first, n, need=None):

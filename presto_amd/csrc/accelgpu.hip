@@ -111,7 +111,7 @@ struct Tuning {
     int use_graph = 1;      // small searches: one captured graph per launch instead of nine stream operations
     int hs_bound = 1;       // harmonic sum over 16-bit upper bounds of the plane, exact where a bound crosses
     int pf_list_cap = 0;    // entries of the coarse bound's list of (row, group)s; 0: 1/64 of all of them (tests lower it)
-    int pf_limit_ppm = 10000; // the coarse bound's list is of no use beyond this many entries per million (row, group)s: the
+    int pf_limit_ppm = 8000;  // the coarse bound's list is of no use beyond this many entries per million (row, group)s: the
                             // walk is given up and the bounded sum runs over the whole plane
     int pf_sample = 1;      // ask a sample of the (row, group)s how long the list would be before walking them all
     int pf_memory = 1;      // a context whose coarse bound was given up leaves it out of its next trials (4, 8, ... 64 of them)

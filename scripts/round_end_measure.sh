@@ -9,3 +9,5 @@ tail -25 gpurun_out/r03f/dense_sweep.txt
 timeout -k 10 300 python scripts/time_pipeline.py 128 > gpurun_out/r03f/pipeline_rate.txt 2>&1
 tail -12 gpurun_out/r03f/pipeline_rate.txt
 bash scripts/profile_round.sh r03f
+timeout -k 10 600 python scripts/range_split_measure.py cfg4 > gpurun_out/r03f/range_split.txt 2>&1
+tail -4 gpurun_out/r03f/range_split.txt
