@@ -536,6 +536,19 @@ template <class P> __device__ __forceinline__ void window_maxima(const unsigned 
 }
 constexpr int kMaximaLdsBytes = 2 * (8192 / 4 + 2); // the table above for the 8192-point plan
 
+// The bank as k_correlate_rr reads it: folded[z][k] = K_z[k] + K_z[k + n/2], folded[z][k + n/2] = K_z[k] - K_z[k + n/2]
+// for k < n/2 (n = the transform length).  One thread per k < n/2 and row.
+__global__ __launch_bounds__(256) void k_fold_bank(const c32 *__restrict__ bank, c32 *__restrict__ folded, int n)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n / 2)
+        return;
+    const size_t row = (size_t) blockIdx.y * (size_t) n;
+    const c32 a = bank[row + k], b = bank[row + k + n / 2];
+    folded[row + k] = a + b;
+    folded[row + k + n / 2] = a - b;
+}
+
 // ---------------------------------------------------------------------------
 // Correlation: one workgroup per (template z, chunk of blocks).  The template's
 // spectrum stays in registers for the whole chunk.  For each block:
@@ -614,6 +627,11 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate(
 // traffic per transform drops from ~160 KB to the 64 KB template row.  KEEPK (template
 // row in registers too, for the block loop) does not fit the register file and is kept
 // only as a compile-time experiment.
+// `bank` is the FOLDED bank (k_fold_bank): inputs k and k + N/2 of the inverse transform are products of the
+// same bin of the block spectrum (the zero-interleaved block's spectrum has period N/2), and the transform's
+// innermost butterflies are exactly the pairs (k, k + N/2); so D * conj(K[k]) +- D * conj(K[k + N/2]) =
+// D * conj(K[k] +- K[k + N/2]) is formed with the sum and the difference taken once per bank instead of once
+// per transform (16 packed additions and 16 subtractions fewer per thread and transform).
 //   pw1: [R1/4+2][M1]  rows 0..R1/4-2: exp(+2*pi*i*b*4*hi/N), hi = 1..R1/4-1;
 //                      then three rows exp(+2*pi*i*b*lo/N), lo = 1..3
 //   pw2: [R2/4+2][R3]  the same for exp(+2*pi*i*d*e/M1)
@@ -790,7 +808,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
             }
         };
         if constexpr (PAIR) {
-            afft::fft3x<P, +1, SER, true>(
+            afft::fft3x<P, +1, SER, true, true>(
                 lds, load, tw1, tw2, mid,
                 [&](auto fc, c32 v, c32 w) {
                     constexpr int f = decltype(fc)::value;
@@ -804,7 +822,7 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
                 },
                 stamp);
         } else {
-            afft::fft3x<P, +1, SER>(
+            afft::fft3x<P, +1, SER, false, true>(
                 lds, load, tw1, tw2, mid,
                 [&](int n, c32 v) {
                     const float pw = power_of(v);

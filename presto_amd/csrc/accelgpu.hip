@@ -129,6 +129,7 @@ struct accelgpu_ctx {
     // kernel bank
     int zmax = -1, numz = 0, fftlen = 0, halfwidth = 0;
     c32 *d_bank = nullptr;
+    c32 *d_bankf = nullptr; // the bank folded for the register-form correlate kernels (k_fold_bank): second half of d_bank's allocation
     Twiddles tw_inv, tw_fwd_full, tw_fwd_half;
     PowTables pw_inv;
 
@@ -281,6 +282,7 @@ struct accelgpu_ctx {
         int xlen = 0;      // transform length used here (>= fftlen)
         int halfwidth = 0; // kern[0].kern_half_width
         c32 *d_bank = nullptr;
+        c32 *d_fold = nullptr; // folded copy (banks of the fundamental's length only), in the same allocation
         bool owned = false;
     };
     std::deque<SubBank> subbanks;
@@ -610,7 +612,7 @@ int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const i
     }
 #define LAUNCH_RR(PLAN, ZL, SPLIT, PAIR)                                                       \
     hipLaunchKernelGGL((accelk::k_correlate_rr<PLAN, false, 16, ZL, afft::NoStamp, SPLIT, PAIR>), rgrid, dim3(PLAN::NT),   \
-                       PLAN::LDS_BYTES + std::min(std::max(tn.corr_lds, 0), 20000), ctx->stream, ctx->d_bank, d_blockfft, d_col, d_ncols,   \
+                       PLAN::LDS_BYTES + std::min(std::max(tn.corr_lds, 0), 20000), ctx->stream, ctx->d_bankf, d_blockfft, d_col, d_ncols,   \
                        nblk, chunk, d_plane, rlen, ctx->halfwidth, ctx->pw_inv.pw1,            \
                        ctx->pw_inv.pw2, ctx->numz, tile_z, tile_c, afft::NoStamp(), d_hi, d_lo, (unsigned short *) nullptr, (int64_t) 0, zl ? d_zrange : nullptr)
     // 8192 points, loop over templates: the last pass hands a thread adjacent outputs, stored two
@@ -619,7 +621,7 @@ int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const i
     if (rr && zl && ctx->fftlen == 8192 && pair && d_hi && d_mx) {
         // with the largest upper half of every four outputs, for the coarse bound in front of the harmonic sum
         hipLaunchKernelGGL((accelk::k_correlate_rr<P8K, false, 16, true, afft::NoStamp, true, true, true>), rgrid, dim3(P8K::NT),
-                           P8K::LDS_BYTES + accelk::kMaximaLdsBytes, ctx->stream, ctx->d_bank, d_blockfft, d_col,
+                           P8K::LDS_BYTES + accelk::kMaximaLdsBytes, ctx->stream, ctx->d_bankf, d_blockfft, d_col,
                            d_ncols, nblk, chunk, d_plane, rlen, ctx->halfwidth, ctx->pw_inv.pw1, ctx->pw_inv.pw2, ctx->numz,
                            tile_z, tile_c, afft::NoStamp(), d_hi, d_lo, d_mx, mxlen, d_zrange);
     } else if (rr && zl && ctx->fftlen == 8192 && pair) {
@@ -1776,12 +1778,13 @@ int accelgpu_build_kernels(accelgpu_ctx *ctx, int zmax)
     }
     free_subbanks(ctx);
     if (ctx->d_bank) HIPCHK(hipFree(ctx->d_bank));
-    ctx->d_bank = nullptr;
+    ctx->d_bank = ctx->d_bankf = nullptr;
     const size_t bank_elems = (size_t) numz * fftlen;
-    if (hipMalloc((void **) &ctx->d_bank, bank_elems * sizeof(c32)) != hipSuccess) {
-        set_error("cannot allocate the kernel bank (%zu bytes)", bank_elems * sizeof(c32));
+    if (hipMalloc((void **) &ctx->d_bank, 2 * bank_elems * sizeof(c32)) != hipSuccess) { // the bank and its folded copy
+        set_error("cannot allocate the kernel bank (%zu bytes)", 2 * bank_elems * sizeof(c32));
         return ACCELGPU_ERR_NOMEM;
     }
+    ctx->d_bankf = ctx->d_bank + bank_elems;
     DevTemp<int> hwbuf;
     HIPCHK(hwbuf.alloc((size_t) numz));
     int *d_hw = hwbuf.p;
@@ -1799,6 +1802,9 @@ int accelgpu_build_kernels(accelgpu_ctx *ctx, int zmax)
         hipLaunchKernelGGL((accelk::k_fft_rows<P16K, -1>), dim3(numz), dim3(P16K::NT),
                            P16K::LDS_BYTES, ctx->stream, ctx->d_bank, ctx->tw_fwd_full.tw1,
                            ctx->tw_fwd_full.tw2);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(accelk::k_fold_bank, dim3((unsigned) ((fftlen / 2 + 255) / 256), (unsigned) numz), dim3(256), 0, ctx->stream,
+                       ctx->d_bank, ctx->d_bankf, fftlen);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->zmax = zmax;

@@ -124,7 +124,10 @@ constexpr float kSin32[32] = {
 // compile time so v[] lives in VGPRs.
 // SER: sizes >= SER run their two half-size sub-transforms one after the other
 // (scheduling barrier between them): fewer live temporaries, less overlap.  0 = off.
-template <int N, int DIR, int SER = 0> struct Dft {
+// PRE2: the innermost butterflies -- v[j] +- v[j + N/2], the first thing the recursion computes -- have been
+// taken already: v[j] comes in as that sum and v[j + N/2] as that difference (a caller whose inputs are
+// products with a table can fold the butterfly into the table: see k_fold_bank).
+template <int N, int DIR, int SER = 0, bool PRE2 = false> struct Dft {
     template <int K> static __device__ __forceinline__ void combine(c32 *v, const c32 *e, const c32 *o)
     {
         c32 t;
@@ -170,24 +173,26 @@ template <int N, int DIR, int SER = 0> struct Dft {
             e[i] = v[2 * i];
             o[i] = v[2 * i + 1];
         }
-        Dft<N / 2, DIR, SER>::run(e);
+        Dft<N / 2, DIR, SER, PRE2>::run(e);
         if constexpr (SER > 0 && N >= SER)
             __builtin_amdgcn_sched_barrier(0);
-        Dft<N / 2, DIR, SER>::run(o);
+        Dft<N / 2, DIR, SER, PRE2>::run(o);
         if constexpr (SER > 0 && N >= SER)
             __builtin_amdgcn_sched_barrier(0);
         combine<0>(v, e, o);
     }
 };
-template <int DIR, int SER> struct Dft<2, DIR, SER> {
+template <int DIR, int SER, bool PRE2> struct Dft<2, DIR, SER, PRE2> {
     static __device__ __forceinline__ void run(c32 *v)
     {
-        const c32 a = v[0], b = v[1];
-        v[0] = a + b;
-        v[1] = a - b;
+        if constexpr (!PRE2) {
+            const c32 a = v[0], b = v[1];
+            v[0] = a + b;
+            v[1] = a - b;
+        }
     }
 };
-template <int DIR, int SER> struct Dft<1, DIR, SER> {
+template <int DIR, int SER, bool PRE2> struct Dft<1, DIR, SER, PRE2> {
     static __device__ __forceinline__ void run(c32 *) {}
 };
 
@@ -319,7 +324,8 @@ template <int F, int NF, class Store> __device__ __forceinline__ void pair_loop(
         pair_loop<F + 1, NF>(store, v);
     }
 }
-template <class P, int DIR, int SER = 0, bool PAIR = false, class Load, class Tw1, class Tw2, class Mid,
+// PRE2: load() returns the inputs with pass 1's innermost butterflies taken (see Dft).
+template <class P, int DIR, int SER = 0, bool PAIR = false, bool PRE2 = false, class Load, class Tw1, class Tw2, class Mid,
           class Store, class Stamp = NoStamp>
 __device__ __forceinline__ void fft3x(c32 *lds, Load load, Tw1 tw1, Tw2 tw2, Mid mid, Store store,
                                       Stamp stamp = Stamp())
@@ -333,7 +339,7 @@ __device__ __forceinline__ void fft3x(c32 *lds, Load load, Tw1 tw1, Tw2 tw2, Mid
 #pragma unroll
         for (int a = 0; a < P::R1; a++)
             v[u * P::R1 + a] = load(u, a, b);
-        Dft<P::R1, DIR, SER>::run(&v[u * P::R1]);
+        Dft<P::R1, DIR, SER, PRE2>::run(&v[u * P::R1]);
         tw1(u, b, &v[u * P::R1]);
         stamp(1); // inputs arrived, pass-1 arithmetic done
 #pragma unroll
