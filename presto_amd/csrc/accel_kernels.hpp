@@ -343,8 +343,12 @@ __device__ __forceinline__ float power_of(c32 v) { return __builtin_fmaf(v.x, v.
 // reaches the range check as a large unsigned number; the others share one register per
 // 4096 bytes (never negative) and carry the rest as the instruction's immediate.
 // ---------------------------------------------------------------------------
+// Outputs n >= 2048 + kUseLen lie behind every block's columns (the shift is at most 2048, a block has at most
+// kUseLen columns): of a 16384-point transform that is 13 of a thread's 32 outputs, which callers skip when the
+// kernel is compiled (KEPT) -- their last-pass arithmetic, powers and stores with them.
 template <class P, int ES = 4> struct PlaneStore { // ES: bytes per stored element
-    static constexpr int NEAR = (P::N < 2048 ? P::N : 2048) / P::NT, NG = P::N >= 1024 ? P::N / 1024 : 1;
+    static constexpr int KEPT = P::N < 2048 + kUseLen ? P::N : 2048 + kUseLen; // outputs at or past this are never stored
+    static constexpr int NEAR = (P::N < 2048 ? P::N : 2048) / P::NT, NG = KEPT >= 1024 ? (KEPT + 1023) / 1024 : 1;
     int vnear[NEAR], vgrp[NG];
     __device__ __forceinline__ PlaneStore(int t, int shift)
     {
@@ -505,7 +509,9 @@ __device__ __forceinline__ void window_maxima_one(const uint32_t *gmx32, __amdgp
 {
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     constexpr int NP = P::N / 8; // pairs of groups
-    if constexpr (J < NP / P::NT) {
+    // (a block has kGpb entries and starts at most 512 groups into the transform: pairs beyond that are never stored)
+    constexpr int NJ = NP / P::NT < ((kGpb + 512 + 2) / 2 + P::NT - 1) / P::NT ? NP / P::NT : ((kGpb + 512 + 2) / 2 + P::NT - 1) / P::NT;
+    if constexpr (J < NJ) {
         const int pidx = t + P::NT * J;
         const uint32_t d0 = gmx32[pidx], d1 = gmx32[pidx + 1];   // groups 2p, 2p + 1 | 2p + 2, 2p + 3
         const uint32_t mid = __builtin_amdgcn_alignbit(d1, d0, 16); // groups 2p + 1, 2p + 2
@@ -535,6 +541,24 @@ template <class P> __device__ __forceinline__ void window_maxima(const unsigned 
         window_maxima_one<P, 0, false>(gmx32, rs, t, o0, o1);
 }
 constexpr int kMaximaLdsBytes = 2 * (8192 / 4 + 2); // the table above for the 8192-point plan
+constexpr int kMaximaLdsBytes16k = 2 * (16384 / 4 + 2); // ... and for the 16384-point plan
+
+// The same table for a plan whose last pass hands a thread single outputs n = t + c (c a compile-time multiple of the
+// workgroup's size; the 16384-point plan): the four outputs of a group sit in four neighbouring lanes, two DPP
+// steps bring their largest to all four, and all four write it (the same value to the same place).  Outputs
+// outside the block's columns do not count; outputs past anything a block can keep (c >= 2048 + kUseLen: the
+// shift is at most 2048) are skipped when the kernel is compiled.
+template <class P> __device__ __forceinline__ void single_maxima(unsigned short *gmx, int t, int c, float p, int col_t, int ncols)
+{
+    if (c >= 2048 + kUseLen)
+        return;
+    float m = p;
+    if (c < 2048 || c + P::NT > kUseLen) // outputs that can lie before or behind the block's columns
+        m = (unsigned int) (col_t + c) < (unsigned int) ncols ? m : 0.f;
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(m) : "v"(m));
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(m) : "v"(m));
+    gmx[(t >> 2) + (c >> 2)] = (unsigned short) (__float_as_uint(m) >> 16);
+}
 
 // The bank as k_correlate_rr reads it: folded[z][k] = K_z[k] + K_z[k + n/2], folded[z][k + n/2] = K_z[k] - K_z[k + n/2]
 // for k < n/2 (n = the transform length).  One thread per k < n/2 and row.
@@ -650,7 +674,8 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
     unsigned short *__restrict__ hi = nullptr, unsigned short *__restrict__ lo = nullptr,
     unsigned short *__restrict__ mx = nullptr, int64_t mxlen = 0, const int2 *__restrict__ zrange = nullptr)
 {
-    static_assert(!MAXIMA || (PAIR && SPLIT && ZL), "group maxima come with the paired stores into split planes");
+    static_assert(!MAXIMA || (SPLIT && ZL), "group maxima come with the template loop's stores into split planes");
+    static_assert(!MAXIMA || PAIR || (P::B3 == 1 && P::NT % 4 == 0), "single stores: a group's four outputs in four neighbouring lanes");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     c32 *lds = reinterpret_cast<c32 *>(smem);
     static_assert(P::B1 == 1, "one pass-1 butterfly per thread");
@@ -825,11 +850,15 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
             afft::fft3x<P, +1, SER, false, true>(
                 lds, load, tw1, tw2, mid,
                 [&](int n, c32 v) {
+                    if (n - t >= PlaneStore<P>::KEPT) // (a compile-time constant once the last pass is unrolled)
+                        return;
                     const float pw = power_of(v);
                     if constexpr (SPLIT)
                         put16.split(rsrc_hi, rsrc_lo, n - t, pw);
                     else
                         put(rsrc, n - t, pw);
+                    if constexpr (MAXIMA)
+                        single_maxima<P>(gmx, t, n - t, pw, t - shift, ncols);
                 },
                 stamp);
         }

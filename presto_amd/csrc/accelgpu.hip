@@ -624,6 +624,12 @@ int launch_correlate(accelgpu_ctx *ctx, int nblk, const c32 *d_blockfft, const i
                            P8K::LDS_BYTES + accelk::kMaximaLdsBytes, ctx->stream, ctx->d_bankf, d_blockfft, d_col,
                            d_ncols, nblk, chunk, d_plane, rlen, ctx->halfwidth, ctx->pw_inv.pw1, ctx->pw_inv.pw2, ctx->numz,
                            tile_z, tile_c, afft::NoStamp(), d_hi, d_lo, d_mx, mxlen, d_zrange);
+    } else if (rr && zl && ctx->fftlen == 16384 && d_hi && d_mx) {
+        // the same from the 16384-point plan's single stores (a group's four outputs in four neighbouring lanes)
+        hipLaunchKernelGGL((accelk::k_correlate_rr<P16K, false, 16, true, afft::NoStamp, true, false, true>), rgrid, dim3(P16K::NT),
+                           P16K::LDS_BYTES + accelk::kMaximaLdsBytes16k, ctx->stream, ctx->d_bankf, d_blockfft, d_col,
+                           d_ncols, nblk, chunk, d_plane, rlen, ctx->halfwidth, ctx->pw_inv.pw1, ctx->pw_inv.pw2, ctx->numz,
+                           tile_z, tile_c, afft::NoStamp(), d_hi, d_lo, d_mx, mxlen, d_zrange);
     } else if (rr && zl && ctx->fftlen == 8192 && pair) {
         if (d_hi) LAUNCH_RR(P8K, true, true, true);
         else LAUNCH_RR(P8K, true, false, true);
@@ -794,7 +800,10 @@ bool coarse_bound_shape_ok(int numharmstages, int64_t search_columns, int64_t rl
     // 2 to 16 harmonics: with 32 the sum of 32 maxima is too loose a bound (most groups are listed).  (With 2 and 4 it
     // pays since a lane sums two adjacent groups from 8-byte loads: 0.40 against 0.93 ms and 0.48 against 1.27 ms
     // on a 2^23-point, zmax 200 plane, for 0.15-0.19 ms more of plane generation.)
-    return search_columns >= ((int64_t) 1 << 22) && fftlen == 8192;
+    // 16384-point transforms (zmax above 300) write the maxima from single stores, which costs plane generation a
+    // quarter more: 16 harmonics gain by it (zmax 400, 2^23 points: 18.1 -> 16.5 ms per search; zmax 1200: 54.7 -> 50.4),
+    // 8 harmonics break even (15.2 -> 15.4), fewer lose
+    return search_columns >= ((int64_t) 1 << 22) && (fftlen == 8192 || (fftlen == 16384 && numharmstages == 5));
 }
 bool prefilter_wanted(const accelgpu_ctx *ctx)
 {
@@ -807,11 +816,11 @@ bool prefilter_wanted(const accelgpu_ctx *ctx)
         return true;
     if (ctx->pf_off)
         return false; // it was given up on this context's last trials
-    return ctx->tune.hs_bound == 1 && ctx->tune.corr_pair != 0;
+    return ctx->tune.hs_bound == 1 && (ctx->fftlen == 16384 || ctx->tune.corr_pair != 0);
 }
 bool maxima_from_plane_generation(const accelgpu_ctx *ctx)
 {
-    return prefilter_wanted(ctx) && ctx->fftlen == 8192 && ctx->tune.corr_pair != 0;
+    return prefilter_wanted(ctx) && (ctx->fftlen == 16384 || (ctx->fftlen == 8192 && ctx->tune.corr_pair != 0));
 }
 
 int launch_prefilter(accelgpu_ctx *ctx, int nstages, const accelk::HarmParams &prm, const HitTarget &out, unsigned int cap,
@@ -1553,6 +1562,7 @@ int accelgpu_create(accelgpu_ctx **out, int device)
     if ((rc = allow_lds(accelk::k_correlate_rr<P8K, false, 16, true, afft::NoStamp, false, true>, P8K::LDS_BYTES + 20000))) return rc;
     if ((rc = allow_lds(accelk::k_correlate_rr<P8K, false, 16, true, afft::NoStamp, true, true, true>, P8K::LDS_BYTES + 20000))) return rc;
     if ((rc = allow_lds(accelk::k_correlate_rr<P16K, false, 16, true, afft::NoStamp, true>, P16K::LDS_BYTES + 20000))) return rc;
+    if ((rc = allow_lds(accelk::k_correlate_rr<P16K, false, 16, true, afft::NoStamp, true, false, true>, P16K::LDS_BYTES + 20000))) return rc;
     if ((rc = allow_lds(accelk::k_fft_rows<P8K, -1>, P8K::LDS_BYTES))) return rc;
     if ((rc = allow_lds(accelk::k_fft_rows<P16K, -1>, P16K::LDS_BYTES))) return rc;
     if ((rc = allow_lds(speck::k_bigfft_cols<P8K>, P8K::LDS_BYTES))) return rc;

@@ -154,8 +154,8 @@ def test_plane_written_by_the_host(gpu, numharm):
 
 def test_coarse_bound_list_overflow_and_long_transforms(gpu):
     """The coarse bound's list of (row, group)s to sum exactly has a capacity: beyond it the plain
-    bounded sum runs instead (same hits).  And with 16384-point transforms (zmax 1200) plane
-    generation does not write the group maxima: they are taken from the plane."""
+    bounded sum runs instead (same hits).  And with 16384-point transforms (zmax 1200, 400) plane
+    generation writes the group maxima from single stores (four neighbouring lanes hold a group)."""
     N, dt = 1 << 19, 1e-4
     fft = synth.noise_fft(N // 2, 84)
     _configure_with_thresholds(gpu, N // 2, N, dt, 10, 16, [9.0, 12.0, 17.0, 26.0, 41.0], fhi=2000.0)
@@ -184,6 +184,13 @@ def test_coarse_bound_list_overflow_and_long_transforms(gpu):
     res = _hits_by_mode(gpu, modes=(0, 1, 4))
     assert len(res[0]) > 50 and gpu.get_tuning("pf_listed") >= 0
     _assert_same(res)
+    for numharm, lo in ((16, 37.0), (4, 1.0)):   # another shift (zmax 400: 480 outputs dropped in front), a search that starts high
+        setup = gpu.configure(N // 2, N, dt, 400, numharm, sigma=1.5, flo=lo, fhi=4000.0)
+        assert setup.fftlen == 16384
+        gpu.load_fft(fft)
+        res = _hits_by_mode(gpu, modes=(0, 3, 4))
+        assert len(res[0]) > 50 and gpu.get_tuning("hs_prefilter_active") == 1 and gpu.get_tuning("pf_listed") > 0
+        _assert_same(res)
 
 
 def test_block_range_and_chunked_sum(gpu):
