@@ -76,7 +76,7 @@ int main(int argc, char **argv)
     for (int rep = 0; rep < 3; rep++) {
         CK(hipEventRecord(e0));
         hipLaunchKernelGGL(plain, dim3(grid), dim3(256), P8K::LDS_BYTES + lds_pad, 0, bank, blockfft, col, ncols, nblk, chunk,
-                           plane, rlen, halfwidth, pw1, pw2, numz, tz, tc, afft::NoStamp(), (unsigned short *) nullptr);
+                           plane, rlen, halfwidth, pw1, pw2, numz, tz, tc, afft::NoStamp(), (unsigned short *) nullptr, (unsigned short *) nullptr, (unsigned short *) nullptr, (int64_t) 0, (const int2 *) nullptr);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms_plain, e0, e1));
@@ -84,7 +84,7 @@ int main(int argc, char **argv)
     for (int rep = 0; rep < 2; rep++) {
         CK(hipEventRecord(e0));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), P8K::LDS_BYTES + lds_pad, 0, bank, blockfft, col, ncols, nblk, chunk,
-                           plane, rlen, halfwidth, pw1, pw2, numz, tz, tc, CycleStamp{stamps, 0}, (unsigned short *) nullptr);
+                           plane, rlen, halfwidth, pw1, pw2, numz, tz, tc, CycleStamp{stamps, 0}, (unsigned short *) nullptr, (unsigned short *) nullptr, (unsigned short *) nullptr, (int64_t) 0, (const int2 *) nullptr);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms_stamp, e0, e1));
