@@ -116,7 +116,7 @@ int accelgpu_synchronize(accelgpu_ctx *ctx);
  *                      fetching the lower halves wherever a bound sum crosses a threshold: the
  *                      same hits from half the bytes.  On large planes searched with 2 to 16
  *                      harmonics (8192-point transforms; 16384-point ones, i.e. zmax above 300,
- *                      with 16 harmonics) a coarser bound runs in front: plane
+ *                      with 8 or 16 harmonics) a coarser bound runs in front: plane
  *                      generation also writes the largest upper half of every eight columns, in
  *                      steps of four; sums of those (and, for harmonics up to 1/4, of the source
  *                      cells' own upper halves) single out the few (row, four columns) that could

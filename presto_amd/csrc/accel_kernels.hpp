@@ -849,16 +849,17 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
         } else {
             afft::fft3x<P, +1, SER, false, true>(
                 lds, load, tw1, tw2, mid,
-                [&](int n, c32 v) {
-                    if (n - t >= PlaneStore<P>::KEPT) // (a compile-time constant once the last pass is unrolled)
-                        return;
-                    const float pw = power_of(v);
-                    if constexpr (SPLIT)
-                        put16.split(rsrc_hi, rsrc_lo, n - t, pw);
-                    else
-                        put(rsrc, n - t, pw);
-                    if constexpr (MAXIMA)
-                        single_maxima<P>(gmx, t, n - t, pw, t - shift, ncols);
+                [&](auto uc, auto fc, c32 v) { // output n = t + c
+                    constexpr int c = P::NT * decltype(uc)::value + P::R1 * P::R2 * decltype(fc)::value;
+                    if constexpr (c < PlaneStore<P>::KEPT) {
+                        const float pw = power_of(v);
+                        if constexpr (SPLIT)
+                            put16.split(rsrc_hi, rsrc_lo, c, pw);
+                        else
+                            put(rsrc, c, pw);
+                        if constexpr (MAXIMA)
+                            single_maxima<P>(gmx, t, c, pw, t - shift, ncols);
+                    }
                 },
                 stamp);
         }

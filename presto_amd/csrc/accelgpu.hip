@@ -801,9 +801,9 @@ bool coarse_bound_shape_ok(int numharmstages, int64_t search_columns, int64_t rl
     // pays since a lane sums two adjacent groups from 8-byte loads: 0.40 against 0.93 ms and 0.48 against 1.27 ms
     // on a 2^23-point, zmax 200 plane, for 0.15-0.19 ms more of plane generation.)
     // 16384-point transforms (zmax above 300) write the maxima from single stores, which costs plane generation a
-    // quarter more: 16 harmonics gain by it (zmax 400, 2^23 points: 18.1 -> 16.5 ms per search; zmax 1200: 54.7 -> 50.4),
-    // 8 harmonics break even (15.2 -> 15.4), fewer lose
-    return search_columns >= ((int64_t) 1 << 22) && (fftlen == 8192 || (fftlen == 16384 && numharmstages == 5));
+    // tenth to a sixth more: 16 and 8 harmonics gain by it (zmax 400, 2^23 points: 18.2 -> 15.0 and 15.3 -> 13.8 ms per
+    // search; zmax 1200, 16 harmonics: 54.6 -> 45.6), fewer do not
+    return search_columns >= ((int64_t) 1 << 22) && (fftlen == 8192 || (fftlen == 16384 && numharmstages >= 4));
 }
 bool prefilter_wanted(const accelgpu_ctx *ctx)
 {
@@ -990,8 +990,9 @@ int launch_harmsum(accelgpu_ctx *ctx, int nstages, int64_t col0, int64_t ncols, 
             // per SIMD (64 registers).  2^23 points, zmax 200: 16 harmonics 3.49 (two columns) against
             // 4.2 ms (one), 8 harmonics 2.03 against 2.95 ms; 2^21 points, zmax 50: 0.315 against 0.245 ms.
             // hs_bound = 2 / 3 force the one-column / the wide kernel.
-            const bool wide = ctx->tune.hs_bound == 3 ||
-                              (ctx->tune.hs_bound != 2 && nstages >= 4 && ncols >= ((int64_t) 1 << 22));
+            // (with few harmonics the wide form gains most: 1 / 2 / 4 harmonics 0.73 / 0.86 / 1.12 against 1.85 / 2.04 /
+            // 2.37 ms on that plane -- what a search runs when the coarse bound does not apply or was given up)
+            const bool wide = ctx->tune.hs_bound == 3 || (ctx->tune.hs_bound != 2 && ncols >= ((int64_t) 1 << 22));
             switch (nstages) {
             case 1: if (wide) LAUNCH_HSBW(1, 4); else LAUNCH_HSB(1); break;
             case 2: if (wide) LAUNCH_HSBW(2, 4); else LAUNCH_HSB(2); break;

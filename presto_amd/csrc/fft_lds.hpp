@@ -16,6 +16,7 @@
 // lane groups of 32; 32 banks and lane groups of 16 for ds_write_b64).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 namespace afft {
 
@@ -325,6 +326,19 @@ template <int F, int NF, class Store> __device__ __forceinline__ void pair_loop(
     }
 }
 // PRE2: load() returns the inputs with pass 1's innermost butterflies taken (see Dft).
+// A store functor that takes its output's place as compile-time constants -- store(PairIndex<u>(), PairIndex<f>(), v)
+// for output t + NT*u + R1*R2*f -- gets them from a recursion instead of a loop: whatever it derives from them
+// (which offset register, whether a range check is needed) is then decided when the kernel is compiled even if
+// the optimiser would not unroll the loop.  Functors that take (n, v) are called from the plain loop.
+template <class P, int U, int F, class Store> __device__ __forceinline__ void single_loop(Store &store, const c32 *v)
+{
+    if constexpr (F < P::R3) {
+        store(PairIndex<U>(), PairIndex<F>(), v[U * P::R3 + F]);
+        single_loop<P, U, F + 1>(store, v);
+    } else if constexpr (U + 1 < P::B3) {
+        single_loop<P, U + 1, 0>(store, v);
+    }
+}
 template <class P, int DIR, int SER = 0, bool PAIR = false, bool PRE2 = false, class Load, class Tw1, class Tw2, class Mid,
           class Store, class Stamp = NoStamp>
 __device__ __forceinline__ void fft3x(c32 *lds, Load load, Tw1 tw1, Tw2 tw2, Mid mid, Store store,
@@ -403,10 +417,14 @@ __device__ __forceinline__ void fft3x(c32 *lds, Load load, Tw1 tw1, Tw2 tw2, Mid
             for (int d = 0; d < P::R3; d++)
                 v[u * P::R3 + d] = lds_read(&lds[(e * P::R3 + d) * P::S2 + n1]);
             Dft<P::R3, DIR, SER>::run(&v[u * P::R3]);
+            if constexpr (std::is_invocable_v<Store, int, c32>) {
 #pragma unroll
-            for (int f = 0; f < P::R3; f++)
-                store(g + P::R1 * P::R2 * f, v[u * P::R3 + f]);
+                for (int f = 0; f < P::R3; f++)
+                    store(g + P::R1 * P::R2 * f, v[u * P::R3 + f]);
+            }
         }
+        if constexpr (!std::is_invocable_v<Store, int, c32>)
+            single_loop<P, 0, 0>(store, v);
     }
     stamp(8); // pass-3 arithmetic done, outputs stored (issued)
 }

@@ -11,7 +11,7 @@ from presto_amd import synth                 # noqa: E402
 CASES = {"cfg2": (1 << 22, 64e-6, 200, 16), "cfg5": (1 << 23, 64e-6, 1200, 32), "cfg4": (1 << 26, 64e-6, 300, 16),
          "cfg2h8": (1 << 22, 64e-6, 200, 8), "cfg2h32": (1 << 22, 64e-6, 200, 32),
          # 16384-point transforms (zmax above 300) with up to 16 harmonics
-         "z400h16": (1 << 22, 64e-6, 400, 16), "z400h8": (1 << 22, 64e-6, 400, 8), "z1200h16": (1 << 22, 64e-6, 1200, 16),
+         "z400h16": (1 << 22, 64e-6, 400, 16), "z400h8": (1 << 22, 64e-6, 400, 8), "z400h4": (1 << 22, 64e-6, 400, 4), "z1200h16": (1 << 22, 64e-6, 1200, 16),
          "cfg5h16": (1 << 23, 64e-6, 1200, 16)}
 g = pa.AccelSearchGPU(0)
 for name in sys.argv[1:] or ["cfg4", "cfg5"]:

@@ -279,7 +279,8 @@ def test_coarse_bound_shape_predicate():
     assert ok(6, cols, rlen, 8192, 0) == 0 and ok(6, cols, rlen, 8192, 1) == 1      # 32 harmonics: only when forced
     assert ok(5, (1 << 22) - 1, rlen, 8192, 0) == 0 and ok(5, 1 << 22, rlen, 8192, 0) == 1
     assert ok(5, cols, rlen, 16384, 0) == 1 and ok(5, cols, rlen, 16384, 1) == 1    # both transform lengths write the maxima
-    assert ok(4, cols, rlen, 16384, 0) == 0 and ok(4, cols, rlen, 16384, 1) == 1    # (the long one pays only with 16 harmonics)
+    assert ok(4, cols, rlen, 16384, 0) == 1 and ok(3, cols, rlen, 16384, 0) == 0    # (the long one pays with 8 and 16 harmonics)
+    assert ok(3, cols, rlen, 16384, 1) == 1
     assert ok(5, cols, rlen, 4096, 0) == 0 and ok(5, cols, rlen, 4096, 1) == 1      # others: maxima from the plane when forced
     for forced in (0, 1):
         assert ok(5, 1 << 33, (1 << 32) - 1, 8192, forced) == 1
