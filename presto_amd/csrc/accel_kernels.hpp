@@ -1673,10 +1673,17 @@ struct WorkItem {
 // (row, group)s spread evenly over the plane (one per lane: 30 microseconds), its last workgroup scales the
 // count to the whole plane and raises the flag if the list would be longer than `limit`, and the walk's
 // workgroups look at the flag when they begin.
-constexpr int kPfLcap = 2048; // entries of a workgroup's own list in LDS
-struct PfShared {
-    WorkItem lst[kPfLcap];
-    unsigned int ln;    // entries this workgroup wants to list (may exceed kPfLcap: the rest went to work[] directly)
+// Entries of a workgroup's own list in LDS: six per thread (48 KB for the 1024 threads large planes are walked
+// with: two workgroups per CU), 2048 at least.  A workgroup that walks a bright signal's columns lists thousands
+// of (row, group)s, and every entry past its own list costs its wave an atomic on the global counter, in the row
+// loop, while the rest of the device waits for that workgroup at the end of the kernel: with 2048 entries the
+// walk of the benchmark's spectrum (two injected pulsars) took 1.10 ms, with 6144 1.04.
+template <int NT> struct PfCap {
+    static constexpr int value = 6 * NT > 2048 ? 6 * NT : 2048;
+};
+template <int CAP> struct PfShared {
+    WorkItem lst[CAP];
+    unsigned int ln;    // entries this workgroup wants to list (may exceed CAP: the rest went to work[] directly)
     unsigned int gbase;
     unsigned int dead;  // the walk had been given up when this workgroup began
 };
@@ -1689,7 +1696,7 @@ __device__ __forceinline__ void pf_give_up(unsigned int *ctl)
     __hip_atomic_store(&ctl[kPfFlag], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // A workgroup begins: false if the walk was given up before it started.  (Contains a barrier.)
-__device__ __forceinline__ bool pf_begin(PfShared &sh, const unsigned int *ctl)
+template <int CAP> __device__ __forceinline__ bool pf_begin(PfShared<CAP> &sh, const unsigned int *ctl)
 {
     if (threadIdx.x == 0) {
         sh.ln = 0;
@@ -1701,7 +1708,8 @@ __device__ __forceinline__ bool pf_begin(PfShared &sh, const unsigned int *ctl)
 // One row's flagged lanes of a wave (`mask` = ballot of `any`) into the workgroup's list first: one atomic on
 // the global counter per workgroup, not per row.  A workgroup whose list is full (a bright signal fills the rows
 // of its columns) sends the rest of the wave's row straight to the global list, again with one atomic.
-__device__ __forceinline__ void pf_insert(PfShared &sh, unsigned long long mask, bool any, int lane, const WorkItem &w,
+template <int CAP>
+__device__ __forceinline__ void pf_insert(PfShared<CAP> &sh, unsigned long long mask, bool any, int lane, const WorkItem &w,
                                           WorkItem *__restrict__ work, unsigned int *__restrict__ ctl, unsigned int limit)
 {
     unsigned int base = 0;
@@ -1710,16 +1718,16 @@ __device__ __forceinline__ void pf_insert(PfShared &sh, unsigned long long mask,
         base = atomicAdd(&sh.ln, (unsigned int) __popcll(mask));
     base = __shfl(base, leader);
     const unsigned int pos = base + (unsigned int) __popcll(mask & ((1ull << lane) - 1ull));
-    if (any && pos < (unsigned int) kPfLcap)
+    if (any && pos < (unsigned int) CAP)
         sh.lst[pos] = w;
-    const unsigned long long over = __ballot(any && pos >= (unsigned int) kPfLcap);
+    const unsigned long long over = __ballot(any && pos >= (unsigned int) CAP);
     if (over) {
         unsigned int gb = 0;
         const int l2 = __ffsll((long long) over) - 1;
         if (lane == l2)
             gb = atomicAdd(&ctl[0], (unsigned int) __popcll(over));
         gb = __shfl(gb, l2);
-        if (any && pos >= (unsigned int) kPfLcap) {
+        if (any && pos >= (unsigned int) CAP) {
             const unsigned int gpos = gb + (unsigned int) __popcll(over & ((1ull << lane) - 1ull));
             if (gpos < limit)
                 work[gpos] = w;
@@ -1731,10 +1739,10 @@ __device__ __forceinline__ void pf_insert(PfShared &sh, unsigned long long mask,
 // The workgroup's list goes to the global one (after the barrier that ends the walk).  Whether it goes is
 // decided by one thread: the flag can change between two threads' looks at it, and there is a barrier below.
 constexpr unsigned int kPfNoBase = 0xFFFFFFFFu;
-template <int NT = 256>
-__device__ __forceinline__ void pf_flush(PfShared &sh, WorkItem *__restrict__ work, unsigned int *__restrict__ ctl, unsigned int limit)
+template <int NT, int CAP>
+__device__ __forceinline__ void pf_flush(PfShared<CAP> &sh, WorkItem *__restrict__ work, unsigned int *__restrict__ ctl, unsigned int limit)
 {
-    const unsigned int n = min(sh.ln, (unsigned int) kPfLcap);
+    const unsigned int n = min(sh.ln, (unsigned int) CAP);
     if (threadIdx.x == 0) {
         unsigned int base = kPfNoBase;
         if (n && !pf_peek(&ctl[kPfFlag])) {
@@ -1765,7 +1773,7 @@ __global__ __launch_bounds__(NT) void k_prefilter_lanes(
     const unsigned int *__restrict__ flags, uint32_t group0)
 {
     constexpr int NH = HarmShape<NSTAGES>::NH, NHS = HarmShape<NSTAGES>::NHS;
-    __shared__ PfShared sh;
+    __shared__ PfShared<PfCap<NT>::value> sh;
     const int lane = threadIdx.x & 63;
     unsigned int tile = blockIdx.x;
     if (xcd_remap) {

@@ -12,7 +12,7 @@ g = pa.AccelSearchGPU(0)
 fft = synth.make_fft(2 * numbins, dt, dict(synth.CONFIGS["cfg2"])["pulsars"], seed=1000)
 g.load_fft(fft)
 g.set_profiling(True)
-for sigma in (12.0, 5.0, 3.0, 2.0, 12.0, 2.0, 12.0, 2.0):
+for sigma in (12.0, 5.0, 3.0, 2.0):
     setup = g.configure(numbins, 2 * numbins, dt, zmax, nh, sigma=sigma, fhi=1e9)
     g.set_tuning("hs_bound", 4)
     g.set_tuning("pf_sample", 0)
