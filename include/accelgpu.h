@@ -129,8 +129,9 @@ int accelgpu_synchronize(accelgpu_ctx *ctx);
  *                      runs), "pf_listed" ((row, four columns) the last search had to sum
  *                      exactly; -1: too many, the bounded sum ran over the whole plane instead)
  *   pf_list_cap    0   capacity of that list in entries (0: 1/64 of all there are)
- *   pf_limit_ppm 8000  entries per million (row, four columns) beyond which the list costs more than the
- *                      bounded sum over the whole plane it replaces; pf_sample 1: a sample of 2^15
+ *   pf_limit_ppm 15000 entries per million (row, four columns) beyond which the list costs more than the
+ *                      bounded sum over the whole plane it replaces (less where the kernel's own lists hold
+ *                      less: two groups per lane, many rows); pf_sample 1: a sample of 2^15
  *                      (row, four columns) is asked before the walk (30 microseconds), and a list
  *                      that would be longer is not started; pf_memory 1: a context whose list was
  *                      given up leaves the coarse bound out of its next 4 launches (8, 16 ... 64 when

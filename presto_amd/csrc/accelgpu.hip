@@ -111,8 +111,9 @@ struct Tuning {
     int use_graph = 1;      // small searches: one captured graph per launch instead of nine stream operations
     int hs_bound = 1;       // harmonic sum over 16-bit upper bounds of the plane, exact where a bound crosses
     int pf_list_cap = 0;    // entries of the coarse bound's list of (row, group)s; 0: 1/64 of all of them (tests lower it)
-    int pf_limit_ppm = 8000;  // the coarse bound's list is of no use beyond this many entries per million (row, group)s: the
-                            // walk is given up and the bounded sum runs over the whole plane
+    int pf_limit_ppm = 15000; // the coarse bound's list is of no use beyond this many entries per million (row, group)s: the
+                            // walk is given up and the bounded sum runs over the whole plane (16 harmonics on a 2^23-point
+                            // zmax 200 plane: 1.5 % listed 5.3 ms per search against 6.4, 2.7 % 6.8 against 6.4)
     int pf_sample = 1;      // ask a sample of the (row, group)s how long the list would be before walking them all
     int pf_memory = 1;      // a context whose coarse bound was given up leaves it out of its next trials (4, 8, ... 64 of them)
     int pf_nt = 0;          // threads per workgroup of that kernel: 0 by the number of groups, 256 / 512 / 1024 that many
@@ -859,16 +860,29 @@ int launch_prefilter(accelgpu_ctx *ctx, int nstages, const accelk::HarmParams &p
     unsigned int wcap = (unsigned int) std::min<size_t>(ctx->work_cap, 0xFFFFFFFFu);
     if (ctx->tune.pf_list_cap > 0)
         wcap = std::min(wcap, (unsigned int) ctx->tune.pf_list_cap);
+    const unsigned int room = wcap; // what the list can hold
     // Beyond this many entries the list costs more than the bounded sum over the whole plane it replaces (every
     // entry is four exact column sums): the kernels give the walk up as soon as they see it coming.
     const double all_entries = (double) ctx->numz * (double) ngroups;
-    if (ctx->tune.hs_bound != 4) // (forced: as long a list as there is room for)
+    if (ctx->tune.hs_bound != 4) { // (forced: as long a list as there is room for)
         wcap = (unsigned int) std::min<double>((double) wcap, std::max(1.0, all_entries * 1e-6 * std::max(ctx->tune.pf_limit_ppm, 0)));
+        // ... and as long as the workgroups' own lists hold it: six entries per thread, i.e. per group with one group per
+        // lane and per two groups with two.  Past four fifths of that on average the fuller workgroups overflow into the
+        // global list, an atomic per wave and row (8 harmonics, two groups per lane, 201 rows: 1.2 % listed 4.9 ms
+        // against the bounded sum's 5.3, 1.9 % 11.9 ms against 5.4)
+        wcap = (unsigned int) std::min<double>((double) wcap, std::max(1.0, 0.8 * 6.0 * (double) ngroups / per_lane));
+    }
     // ... by asking a sample of the (row, group)s before the walk (k_prefilter_sample): 2^15 of them put the list's
     // length within a few per cent where it matters (a list at the limit has hundreds of them)
     const unsigned int nsamples = (unsigned int) std::min<double>(32768.0, all_entries);
     unsigned int gstep = (unsigned int) ((double) ngroups * 0.6180339887) | 1u;
     const unsigned int sample_limit = (unsigned int) std::min<double>(4294967295.0, std::ceil((double) wcap * (double) nsamples / all_entries));
+    // The limit is the sample's question.  A walk that was started is given up only half as much again past it (or
+    // when the list has no room): a list a little over the limit still costs about what the bounded sum would, while
+    // giving up after the walk costs the walk and the bounded sum (8 harmonics, 1.24 % listed against a limit of
+    // 1.19 %: 4.9 ms finished, 6.7 given up).
+    if (ctx->tune.pf_sample)
+        wcap = (unsigned int) std::min<double>((double) room, 1.5 * (double) wcap);
 #define LAUNCH_WALK_AS(NS, NG, NT)                                                                             \
     hipLaunchKernelGGL((accelk::k_prefilter_lanes<NS, NG, NT>), dim3(nt), dim3(NT), 0, ctx->stream, ctx->d_mx, ctx->numz, g,  \
                        ngroups, ctx->d_rowmx, prm, ctx->d_work, ctx->d_ctl, wcap, remap, ctx->d_flags, group0)

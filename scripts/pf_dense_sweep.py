@@ -13,7 +13,7 @@ from presto_amd import synth                 # noqa: E402
 from presto_amd.api import plan              # noqa: E402
 
 numbins, dt, zmax = 1 << 22, 64e-6, 200
-SCALES = (1.0, 0.9, 0.85, 0.8, 0.76, 0.72, 0.68, 0.6)
+SCALES = tuple(float(x) for x in os.environ.get("PF_SCALES", "1.0,0.9,0.88,0.87,0.85,0.8,0.76,0.72,0.68,0.6").split(","))
 g = pa.AccelSearchGPU(0)
 fft = synth.make_fft(2 * numbins, dt, dict(synth.CONFIGS["cfg2"])["pulsars"], seed=1000)
 g.load_fft(fft)
