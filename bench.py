@@ -47,8 +47,11 @@ def cpu_baseline(cfg, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # (a timed region of K pipelined steps costs K steps plus one fill and drain of the pipeline, 3.6 ms -- the first
+    # trial's kernels with nothing beside them, the last trial's download and replay with the GPU idle: at 20 steps
+    # that is 4 % of the region, at 100 under 1 %; the first steps after an idle spell run at lower clocks)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--trials", type=int, default=4, help="distinct spectra resident per GPU")
     ap.add_argument("--log2n", type=int, default=23)
     ap.add_argument("--no-cpu", action="store_true")
@@ -137,6 +140,11 @@ def main():
         if multi:
             merge(warm)             # the collectives' first-use set-up belongs to the warm-up too
     g.timings(reset=True)
+    # (the cycle collector stays off inside the timed region, as in timeit: the loop creates no cycles, and a collection
+    # of the candidate lists kept for the merge pauses the host for longer than the two trials in flight last --
+    # 200 steps: 229-231 searches/s with it, 236-240 without)
+    import gc
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     cpu0 = time.process_time()                 # all threads of this process
@@ -146,6 +154,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     host_cpu_s = time.process_time() - cpu0
+    gc.enable()
     listed = g.get_tuning("pf_last_listed")    # of the last collected trial: (row, four columns) the coarse bound listed
     bounded = g.get_tuning("hs_bound_active") == 1
     prefilter = bounded and listed != -2       # the coarse bound ran in front of the harmonic sum

@@ -268,6 +268,12 @@ def search_files(gpu, files, indices, opts, depth=2):
             collect_trial(gpu, launched, opts, writer, pool)
             optimising, launched = launched, None
 
+    # The cycle collector stays off while files are in flight: the loop creates no reference cycles, and a full
+    # collection of the candidate lists kept for sifting pauses the host for longer than the two searches in
+    # flight last (a 200-trial loop on one GPU: 229-231 trials/s with it, 236-240 without).
+    import gc
+    gc_was_on = gc.isenabled()
+    gc.disable()
     try:
         while True:
             with _timed("wait for reader"):
@@ -289,6 +295,8 @@ def search_files(gpu, files, indices, opts, depth=2):
         yield from ready(all_of_them=True)
     finally:
         writer.shutdown(wait=True)
+        if gc_was_on:
+            gc.enable()
     th.join()
     gpu.synchronize()
     pool.close()
