@@ -695,10 +695,24 @@ __global__ __launch_bounds__(P::NT, 2) void k_correlate_rr(
         // workgroups an XCD holds at one time come from one tile of tile_z owned items x
         // tile_c chunks, so its L2 keeps the few template rows and block spectra of that
         // tile instead of cycling through the whole bank.
-        const int tiles_a = (na + tile_z - 1) / tile_z;
+        // The tiles beyond the last whole eight -- 281 tiles are 35 eights and one -- are dealt workgroup by
+        // workgroup over all XCDs instead: as a whole tile each they would leave one XCD with a tile more than the
+        // others (1/36 of the kernel with seven eighths of the device idle).
+        const int tiles_a = (na + tile_z - 1) / tile_z, tiles_c = (nchunks + tile_c - 1) / tile_c;
+        const int ntiles = tiles_a * tiles_c, eights = ntiles / 8;
         const int per = tile_z * tile_c;
         const int x = blockIdx.x % 8, sq = blockIdx.x / 8;
-        const int tile = (sq / per) * 8 + x, p = sq % per;
+        int tile, p;
+        if (sq / per < eights) {
+            tile = (sq / per) * 8 + x;
+            p = sq % per;
+        } else {
+            const int j = (sq % per) * 8 + x;
+            tile = eights * 8 + j / per;
+            p = j % per;
+            if (tile >= ntiles)
+                return;
+        }
         ia = (tile % tiles_a) * tile_z + p % tile_z;
         cy = (tile / tiles_a) * tile_c + p / tile_z;
         if (ia >= na || cy >= nchunks)
