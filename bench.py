@@ -230,7 +230,7 @@ def main():
         for _ in range(3):
             g.optimize(kept)
         opt_ms = 1e3 * (time.perf_counter() - t2) / 3.0    # one trial's candidates, GPU otherwise idle
-        kf = 12
+        kf = 40                                            # (fill and drain of the two-deep pipeline: 2 % of it)
         g.synchronize()
         t1 = time.perf_counter()
         launch(0)

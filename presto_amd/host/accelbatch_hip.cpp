@@ -315,7 +315,7 @@ class Writer {
     std::thread th_;
 };
 
-// Collect a launched trial: list replay, work file (to the writer), trimming, optimisation queued.
+// Collect a launched trial: list replay, work file (to the writer), trimming.
 void collect_trial(accelgpu_ctx *gpu, Trial &t, const Options &o, PinnedPool &pool, Writer &writer)
 {
     const accelgpu_setup &su = t.setup;
@@ -350,12 +350,21 @@ void collect_trial(accelgpu_ctx *gpu, Trial &t, const Options &o, PinnedPool &po
         if (accelgpu_sort_and_eliminate(cands.data(), ncands, su.numharm > 1 && o.harmremove, &kept))
             die("accelgpu_sort_and_eliminate");
         t.kept.assign(cands.begin(), cands.begin() + kept);
-        if (accelgpu_optimize_launch(gpu, t.kept.data(), kept, o.polish ? 1 : 0)) die("accelgpu_optimize_launch");
-        t.nopt = kept;
     }
     if (!o.quiet)
         printf("%s: %lld cells above threshold, %lld candidates, %lld kept\n", t.path.c_str(), (long long) nhits,
-               (long long) ncands, (long long) t.nopt);
+               (long long) ncands, (long long) t.kept.size());
+}
+
+// Queue the optimisation of the trimmed list (against this trial's spectrum, beside the next
+// trial's search).  One optimisation is out at a time: the one before has been collected.
+void optimise_trial(accelgpu_ctx *gpu, Trial &t, const Options &o)
+{
+    if (t.kept.empty())
+        return;
+    if (accelgpu_optimize_launch(gpu, t.kept.data(), (int64_t) t.kept.size(), o.polish ? 1 : 0))
+        die("accelgpu_optimize_launch");
+    t.nopt = (int64_t) t.kept.size();
 }
 
 // Wait for the optimisation and hand the result files to the writer.
@@ -437,15 +446,19 @@ int main(int argc, char **argv)
     accelgpu_setup su{};
     Birds birds;
     std::unique_ptr<Trial> launched, optimising;
-    // One step for the trials behind the newest launch: the older optimisation's results
-    // out to the files, the collected search's candidates to the device.
+    // One step for the trials behind the newest launch.  The older search is collected first:
+    // the optimisation queued a step ago ran beside it on the device and is over by the time
+    // its results are asked for (waiting for it before the search put its whole length, 3 ms
+    // of dependent steps, on the host's path).
     auto advance = [&] {
+        if (launched)
+            collect_trial(gpu, *launched, o, pool, writer);
         if (optimising) {
             write_trial(gpu, *optimising, writer);
             optimising.reset();
         }
         if (launched) {
-            collect_trial(gpu, *launched, o, pool, writer);
+            optimise_trial(gpu, *launched, o);
             optimising = std::move(launched);
         }
     };
