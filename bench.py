@@ -154,7 +154,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     host_cpu_s = time.process_time() - cpu0
-    gc.enable()
+    # (it stays off through the legs reported beside, which are timed loops of the same kind: a collection of what the
+    # timed region left behind, 30 ms, fell into the 40 trials with optimisation on one box in two)
     listed = g.get_tuning("pf_last_listed")    # of the last collected trial: (row, four columns) the coarse bound listed
     bounded = g.get_tuning("hs_bound_active") == 1
     prefilter = bounded and listed != -2       # the coarse bound ran in front of the harmonic sum
@@ -275,6 +276,7 @@ def main():
         dense_hits = float(np.mean([r[0] for r in dres]))
         setup = saved_setup
         g.set_search(setup)
+    gc.enable()
 
     if rank == 0:
         cells = setup.numz * 7470 * setup.num_search_blocks
