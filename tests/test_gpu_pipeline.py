@@ -95,3 +95,37 @@ def test_native_batch_program_equals_one_run_per_file(tmp_path):
     assert len(made) == 3 * 4 + 2 and made == sorted(n for n in os.listdir(str(b)) if "_ACCEL_" in n)
     for n in made:
         assert open(str(a / n), "rb").read() == open(str(b / n), "rb").read(), n
+
+
+def test_python_pipeline_equals_one_file_at_a_time(tmp_path):
+    """pipeline.search_files (reader thread, two searches queued, each file's optimisation asked for after the
+    next search has been collected) writes byte for byte what pipeline.search_one_file writes for each file on
+    its own, a change of series length in mid-batch and a file without candidates included."""
+    import shutil
+    from presto_amd import api
+    a, b = tmp_path / "single", tmp_path / "piped"
+    a.mkdir()
+    b.mkdir()
+    names = []
+    for k, N in enumerate([1 << 19, 1 << 19, 1 << 19, 1 << 18, 1 << 18, 1 << 19]):
+        dt = 2.5e-4
+        puls = [] if k == 1 else [dict(f=91.3 + k, z=7.0 - 3 * k, amp=0.3, duty=0.05), dict(f=155.0, z=-2.0, amp=0.2, duty=0.1)]
+        root = str(a / ("p%d_DM%.2f" % (k, 3.0 * k)))
+        synth.write_fft(root, synth.make_fft(N, dt, puls, seed=80 + k), N, dt)
+        names.append(os.path.basename(root) + ".fft")
+    for n in os.listdir(str(a)):
+        shutil.copy(str(a / n), str(b / n))
+    flags = ["-zmax", "20", "-numharm", "8", "-sigma", "6.0" , "-fhi", "1900", "-verbosity", "0"]
+    gpu = api.AccelSearchGPU(0)
+    opts = pipeline.parse_args(flags + [str(a / n) for n in names])
+    alone = [pipeline.search_one_file(gpu, str(a / n), opts)[0] for n in names]
+    gpu = api.AccelSearchGPU(0)
+    files = [str(b / n) for n in names]
+    piped = {i: cl for i, cl, _ in pipeline.search_files(gpu, files, list(range(len(files))), opts)}
+    assert sorted(piped) == list(range(len(files)))
+    made = sorted(n for n in os.listdir(str(a)) if "_ACCEL_" in n)
+    assert made == sorted(n for n in os.listdir(str(b)) if "_ACCEL_" in n) and len(made) >= 3 * 4
+    for n in made:
+        assert open(str(a / n), "rb").read() == open(str(b / n), "rb").read(), n
+    for i, cl in enumerate(alone):
+        assert [(c.candnum, c.sigma, c.r, c.z) for c in cl] == [(c.candnum, c.sigma, c.r, c.z) for c in piped[i]]
